@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the MI355X likelihood-tempered SMC engine.
+
+Metric (BASELINE.json): particle-mutation-steps/s (+ ESS-search iterations/s) on the
+Michaelis-Menten model, 1e6 particles per GPU, adaptive tempering + residual-systematic
+resampling, reference default hyper-parameters (configs[1]; with --gpus N the N x 1e6 particles of
+configs[2] are sharded one block per rank: weak scaling).
+
+One "step" = one COMPLETE adaptive-tempering SMC run (prior draw -> gamma = 1) over the resident
+particle population: every stage of the hot path (likelihood sweep, fused ESS search, resampling,
+moments, fused Metropolis sweeps) runs inside the timed region, with device RNG so that nothing but
+a few scalars per stage crosses PCIe.  value = particle-mutation-steps executed / wall time.
+
+Launch:  python bench.py --gpus 1 --steps 3 --warmup 1
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 flop x 2.4 GHz (datasheet)
+HBM_PEAK_GBPS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic FP64 flop of one particle-mutation-step (DESIGN.md "Kernels"):
+FLOP_PER_RK_ATTEMPT = 100        # 6 RHS (3 flop each) + stage sums + y_new + error estimate + controller
+FLOP_PER_PARTICLE_FIXED = 6 * 40 * 14 + 240 * 4 + 6 * 12 + 50   # dense-output points, residuals, logL, accept
+HBM_BYTES_PER_PARTICLE_MH = 24 + 8 + 24 + 8 + 2  # read theta, lk1; write theta, lk1; r_ac read+write
+
+
+def load_mm_data():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "mm_data.npz"))
+    return z["t"], z["P_obs"], z["S0"]
+
+
+def cpu_baseline(sample_seconds_target=15.0):
+    """The reference's per-particle path (SciPy solve_ivp RK45 per particle x experiment, one task per
+    particle on a process pool = the Ray fan-out, Micmem_likelihood.py:83) timed on this box's host
+    cores on a bounded sample of the same workload: one mutation-sweep-equivalent likelihood pass over
+    M posterior-like particles.  The code timed is oracle/oracle.py's NumPy/SciPy counterpart (the
+    reference's files do not travel to this box)."""
+    O = entry.load_oracle()
+    data = O.MMData.load()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    rs = np.random.RandomState(0)
+    per_core_rate = 78.0  # likelihoods/s/core measured in the survey; only used to size the sample
+    m = int(max(cores * 8, min(20000, per_core_rate * cores * sample_seconds_target)))
+    theta = np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((m, 3)) * np.array([0.025, 0.0295, 0.00094])
+    t0 = time.perf_counter()
+    lk = O.mm_loglik_batch_scipy(theta, data, n_workers=cores)
+    dt = time.perf_counter() - t0
+    # C restatement of the same pass on all cores (second, faster CPU figure)
+    t1 = time.perf_counter()
+    lk_c, _, info = O.mm_loglik_batch(np.tile(theta, (8, 1)), data, n_threads=cores)
+    dt_c = time.perf_counter() - t1
+    assert np.max(np.abs(lk - lk_c[:m]) / np.maximum(1, np.abs(lk))) < 1e-9
+    # ESS iteration as the reference writes it (Micmem_SMC_main.py:124-134), N = 1e6, one core
+    lk6 = -np.abs(rs.standard_normal(1_000_000)) * 300
+    d_lk = lk6 - lk6.max()
+    t2 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        w = np.exp(d_lk * 0.01)
+        sw = np.sum(w)
+        w = w / sw
+        ess = 1.0 / np.sum(w ** 2) / 1_000_000
+    dt_e = (time.perf_counter() - t2) / reps
+    return {"value": m / dt, "unit": "particle-mutation-steps/s", "cores": cores, "kind": "port",
+            "sample": f"one likelihood pass (the >98% term of a mutation step) over {m} posterior-like particles, "
+                      f"scipy.solve_ivp RK45 x 6 experiments each, fork pool of {cores} workers, {dt:.1f}s",
+            "c_restatement_value": 8 * m / dt_c, "c_restatement_cores": cores,
+            "ess_iters_per_s_n1e6_1core": 1.0 / dt_e}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--particles-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    pkg = entry.load_package()
+    n_local = args.particles_per_gpu
+    n_global = n_local * world
+    t, P_obs, S0 = load_mm_data()
+    s = pkg.SMCSettings(n_particle=n_global)
+
+    eng = pkg.HipEngine(n_local, 3, device=local_rank, n_global=n_global)
+    eng.set_model_mm(t, P_obs, S0)
+    eng.set_prior(s.priors)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # bootstrap channel only
+
+        def bootstrap(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = pkg.RcclComm(eng, rank, world, bootstrap)
+    else:
+        comm = pkg.SingleComm()
+
+    def one_run(i):
+        return pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=1000 + i)
+
+    for i in range(args.warmup):
+        one_run(-1 - i)
+    eng.timing_enable(True)
+    eng.timing_reset()
+    comm.barrier()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    outs = [one_run(i) for i in range(args.steps)]
+    comm.barrier()
+    eng.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = float(comm.allreduce_max([elapsed])[0])
+    timing = eng.timing_get()
+    eng.timing_enable(False)
+
+    pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)          # global count
+    sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs)
+    ess_iters = sum(o["stats"]["ess_iters"] for o in outs)
+
+    result = None
+    if rank == 0:
+        mh = timing["mh"]
+        mh_ms = mh["ms"] / max(1, mh["launches"])
+        # rank 0's fused-MH launches: algorithmic flop from the device-counted RK45 attempts of those launches
+        att_mh = sum(o["stats"]["rk_attempts_mh"] for o in outs)
+        flop_mh = FLOP_PER_RK_ATTEMPT * att_mh + FLOP_PER_PARTICLE_FIXED * n_local * mh["launches"]
+        flop_per_launch = flop_mh / max(1, mh["launches"])
+        ach_tflops = flop_per_launch / (mh_ms * 1e-3) / 1e12
+        hbm_gbps = HBM_BYTES_PER_PARTICLE_MH * n_local / (mh_ms * 1e-3) / 1e9
+        ess_ms = timing["ess"]["ms"]
+        result = {
+            "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Michaelis-Menten (6 experiments x 40 points), adaptive tempering + "
+                                   "residual-systematic resampling, reference defaults; one step = one full SMC run "
+                                   "prior->gamma=1", "particles_per_gpu": n_local, "particles_total": n_global,
+                       "rng": "device Philox4x32-10", "parallelism": f"particle-sharded x{world}"},
+            "ess_iters_per_s": ess_iters / (ess_ms * 1e-3) if ess_ms > 0 else None,
+            "ess_iters": ess_iters, "ess_kernel_ms_total": ess_ms,
+            "tempering_steps_per_run": [o["step"] for o in outs],
+            "mutation_sweeps": sweeps, "logZ": [o["logZ"] for o in outs],
+            "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(),
+            "kernel_ms": {k: v for k, v in timing.items()},
+            "roofline": {"kernel": "mm_sweep_kernel<1,false> (fused Metropolis + likelihood)", "bound": "fp64-valu",
+                         "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": mh_ms, "launches": mh["launches"],
+                         "algorithmic_flop_per_launch": flop_per_launch,
+                         "hbm": {"algorithmic_bytes_per_launch": HBM_BYTES_PER_PARTICLE_MH * n_local,
+                                 "achieved_GBps": hbm_gbps, "peak_GBps": HBM_PEAK_GBPS,
+                                 "frac": hbm_gbps / HBM_PEAK_GBPS},
+                         "mfma": "unused (largest contraction is 3x3)"},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    comm.barrier()
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

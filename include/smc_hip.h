@@ -1,0 +1,182 @@
+/*
+ * include/smc_hip.h -- C ABI of libsmc_hip.so, the MI355X (gfx950) engine for the particle
+ * inner loop of adaptive likelihood-tempered SMC.
+ *
+ * The reference (maruchitatsuki/python-based-Sequential-Monte-Carlo-method-with-likelihood-tempering)
+ * has no FFI: its boundary is a set of Python names.  Each entry point
+ * below names the reference statements it replaces (file:line relative to the reference root).
+ * The Python host side (python-based-..._amd/binding.py) binds exactly these symbols with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success, non-zero on error, and
+ *     smc_last_error(ctx) returns the message (ctx may be NULL for creation errors);
+ *   - the caller owns host buffers (C-contiguous float64 / int64 / uint8); the library owns all
+ *     device memory inside the opaque context; one context per (process, device); a context is
+ *     not thread-safe;
+ *   - particles are AoS (N,d) at this edge, exactly like the reference's p_pred / p_filt arrays,
+ *     and SoA d x N in HBM (transposed by the upload / download calls);
+ *   - the two particle sets of the reference are addressed by SMC_SET_PRED (p_pred with lk,
+ *     Micmem_settings.py:85; Micmem_SMC_main.py:98) and SMC_SET_FILT (p_filt with lk1,
+ *     Micmem_settings.py:118,127);
+ *   - every arithmetic step is IEEE float64; integers are used only for offspring counts and flags;
+ *   - multi-GPU: one context per rank, each owning the contiguous block
+ *     [rank*n_local, (rank+1)*n_local) of the global particle order.  Entry points that take
+ *     "_local"/"_global" arguments compute this rank's partial; the host combines partials with the
+ *     smc_comm_* collectives (RCCL).  With one rank the same calls are used with world size 1.
+ */
+#ifndef SMC_HIP_H
+#define SMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMC_ABI_VERSION 1
+#define SMC_MAX_DIM 8        /* parameters per particle (3 for Michaelis-Menten, 5 for methanation) */
+#define SMC_MAX_ESS_CAND 16  /* tempering candidates evaluated by one smc_ess_partials call */
+#define SMC_MAX_RANKS 64
+
+#define SMC_SET_PRED 0
+#define SMC_SET_FILT 1
+
+#define SMC_PRIOR_UNIFORM 0 /* {"dist":"uniform","low","high"}  Micmem_settings.py:63-67 */
+#define SMC_PRIOR_NORMAL 1  /* {"dist":"normal","mu","sigma"}   Micmem_settings.py:55-59 */
+
+typedef struct smc_ctx smc_ctx;
+
+int smc_abi_version(void);
+/* NULL ctx: message of the last failed smc_create / context-less call in this thread. */
+const char *smc_last_error(const smc_ctx *ctx);
+
+/* Context with capacity for n_local particles of dimension dim on HIP device `device`.
+ * n_global = world * n_local (pass n_local for a single GPU).  Replaces the buffer allocations of
+ * Micmem_settings.py:85,118-127. */
+int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int dim);
+void smc_destroy(smc_ctx *ctx);
+int smc_synchronize(smc_ctx *ctx);
+/* Name/arch of the device the context runs on (e.g. "gfx950"). */
+int smc_device_info(smc_ctx *ctx, char *name, int name_len, char *arch, int arch_len, int *cu_count);
+
+/* ---- model + prior ------------------------------------------------------------------------ */
+/* Michaelis-Menten data set (Micmem_settings.py:103-115) and solver tolerances (SciPy defaults
+ * rtol=1e-3, atol=1e-6 of the solve_ivp call at Micmem_likelihood.py:24-30).  t and P_obs are
+ * n_ex x n_t row-major, S0 has n_ex entries.  n_ex <= 16, n_t <= 256. */
+int smc_set_model_mm(smc_ctx *ctx, const double *t, const double *P_obs, const double *S0, int n_ex, int n_t,
+                     int est_sigma, double sigma_fixed, double rtol, double atol);
+/* Independent priors, one per parameter: kind[i] in {SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL}; (a,b) =
+ * (low,high) or (mu,sigma).  Used by the support mask of cal_prior (Micmem_SMC_main.py:60-90,
+ * 224-228) and by smc_sample_prior_device. */
+int smc_set_prior(smc_ctx *ctx, const int *kind, const double *a, const double *b, int dim);
+
+/* ---- particle movement -------------------------------------------------------------------- */
+int smc_upload_particles(smc_ctx *ctx, int set, const double *aos, int64_t n);   /* (n,d) -> SoA */
+int smc_download_particles(smc_ctx *ctx, int set, double *aos, int64_t n);
+int smc_upload_lk(smc_ctx *ctx, int set, const double *lk, int64_t n);
+int smc_download_lk(smc_ctx *ctx, int set, double *lk, int64_t n);
+/* r_ac, the ever-accepted flags of the current tempering step (Micmem_SMC_main.py:187,241). */
+int smc_download_accept_flags(smc_ctx *ctx, uint8_t *flags, int64_t n);
+/* p_pred, lk = p_filt.copy(), lk1.copy() (Micmem_SMC_main.py:251-252): device-to-device. */
+int smc_commit_filt_to_pred(smc_ctx *ctx);
+/* Device-RNG prior draw into SMC_SET_PRED (replaces sample_prior, Micmem_settings.py:69-87, in
+ * device-RNG mode): Philox4x32-10 keyed by (seed, global particle index, parameter). */
+int smc_sample_prior_device(smc_ctx *ctx, uint64_t seed, int64_t global_offset);
+
+/* ---- A2: likelihood sweep ----------------------------------------------------------------- */
+/* sim_particle (Micmem_likelihood.py:79-92) on the resident set: lk[i] = log_likelihood_mm_multi(
+ * theta_i) (Micmem_likelihood.py:35-77).  n_failed counts particles with a failed RK45 solve (their
+ * lk is NaN; the reference raises there).  rk_attempts (optional) receives the device-counted number
+ * of RK45 step attempts summed over particles x experiments (flop accounting). */
+int smc_loglik(smc_ctx *ctx, int set, int64_t *n_failed, int64_t *rk_attempts);
+/* Same for a host batch (the drop-in sim_particle surface): particle (n,3) in, lk[n] out and, when
+ * pred != NULL, the model predictions C_l_ as n x n_ex x n_t (P_model, Micmem_likelihood.py:32,74).
+ * Any n up to the context capacity. Does not disturb the resident sets. */
+int smc_mm_loglik_host(smc_ctx *ctx, const double *particle, int64_t n, double *lk, double *pred, int64_t *n_failed,
+                       int64_t *rk_attempts);
+
+/* ---- A3/A4: tempered weights, ESS ---------------------------------------------------------- */
+/* max(lk) over this rank's SMC_SET_PRED block (Micmem_SMC_main.py:116). */
+int smc_max_lk_local(smc_ctx *ctx, double *max_lk);
+/* For k < n_cand: sum_w[k] = sum_i exp((lk_i-max_lk)*gm[k]), sum_w2[k] = sum_i exp(...)^2 over this
+ * rank's block (Micmem_SMC_main.py:118,124-134; ess = sum_w^2 / sum_w2 / N).  n_cand <= SMC_MAX_ESS_CAND. */
+int smc_ess_partials(smc_ctx *ctx, double max_lk, const double *gm, int n_cand, double *sum_w, double *sum_w2);
+
+/* ---- A5: residual-systematic resampling (Micmem_SMC_main.py:147-184) ------------------------ */
+/* Phase 1: with w_i = exp((lk_i-max_lk)*gm)/sum_weight_global, p_is_i = trunc(w_i*N_global) and the
+ * residual w_i - p_is_i/N_global: returns this rank's sum of residuals and of p_is. */
+int smc_resample_phase1(smc_ctx *ctx, double max_lk, double gm, double sum_weight_global, double *residual_sum_local,
+                        int64_t *count_sum_local);
+/* Phase 2: residual_prefix = sum of the residual sums of lower ranks; wrand = rand()/N_global (:156).
+ * Adds the systematic offspring (:165-174) and builds the inclusive offspring scan.  Returns this
+ * rank's total offspring. */
+int smc_resample_phase2(smc_ctx *ctx, double max_lk, double gm, double sum_weight_global, double residual_prefix,
+                        double wrand, int64_t *offspring_local);
+/* Offspring counts p_is (after phase 2), for inspection / parity tests. */
+int smc_download_offspring(smc_ctx *ctx, int64_t *p_is, int64_t n);
+/* Phase 3 (:178-184): this rank's offspring occupy global output slots [out_base, out_base+offspring)
+ * in ancestor order.  Slots owned by this rank are written straight into SMC_SET_FILT; slots owned by
+ * other ranks are exchanged with grouped RCCL send/recv (smc_comm_init must have been called when
+ * world > 1).  out_base_all / offspring_all: arrays of length world (the allgathered values).
+ * Slots >= total offspring keep the content the reference's persistent p_filt would hold
+ * (zeros before the first tempering step, the previous p_pred row afterwards). */
+int smc_resample_phase3(smc_ctx *ctx, const int64_t *out_base_all, const int64_t *offspring_all, int first_step);
+
+/* ---- A6: proposal covariance (np.cov(p_filt.T, bias=True), Micmem_SMC_main.py:212) ---------- */
+/* sums[d] = sum_i theta_i over this rank's SMC_SET_FILT block. */
+int smc_moment_sums_local(smc_ctx *ctx, double *sums);
+/* centered[d*d] (row-major, symmetric) = sum_i (theta_i-mean)(theta_i-mean)^T over this rank's block. */
+int smc_moment_centered_local(smc_ctx *ctx, const double *mean, double *centered);
+
+/* ---- A7-A9: one random-walk Metropolis iteration, fused with the likelihood ------------------ */
+/* Host-RNG (parity) mode.  noise is the (n,d) array np.random.multivariate_normal returned
+ * (Micmem_SMC_main.py:220), rr the n uniforms of :235.  Performs :220-241 on SMC_SET_FILT in place:
+ * proposal = p_filt + noise*mhstep_ratio; support mask p0; proposal reset where p0 == 0; lk2 =
+ * likelihood(proposal); accept r = exp((lk2-lk1)*gamma)*p0 >= rr; select p_filt, lk1; r_ac = max(r_ac, r).
+ * Outputs (local): accepted_now = sum(r), accepted_ever = sum(r_ac). */
+int smc_mh_step_host_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *noise, const double *rr,
+                         int64_t n, int64_t *accepted_now, int64_t *accepted_ever, int64_t *n_failed,
+                         int64_t *rk_attempts);
+/* Device-RNG mode.  noise_i = z_i @ transform (transform is d x d row-major, i.e. NumPy's
+ * sqrt(s)[:,None]*v factor of cov_m), z_i and rr_i from Philox4x32-10 keyed by (seed, global particle
+ * index = global_offset+i, stream).  Everything else as above. */
+int smc_mh_step_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *transform, uint64_t seed,
+                           uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
+                           int64_t *n_failed, int64_t *rk_attempts);
+/* r_ac = zeros (Micmem_SMC_main.py:187). */
+int smc_reset_accept_flags(smc_ctx *ctx);
+/* Copies of the last proposals/lk2 for parity tests (valid after an MH step when enabled). */
+int smc_set_debug_capture(smc_ctx *ctx, int enable);
+int smc_download_debug_proposals(smc_ctx *ctx, double *aos, double *lk2, uint8_t *p0, uint8_t *r, int64_t n);
+
+/* ---- collectives (RCCL over xGMI) ------------------------------------ */
+/* unique id = 128 bytes from smc_comm_get_unique_id on rank 0, broadcast by the launcher. */
+int smc_comm_get_unique_id(uint8_t id[128]);
+int smc_comm_init(smc_ctx *ctx, const uint8_t id[128], int rank, int world);
+int smc_comm_allreduce_sum_f64(smc_ctx *ctx, double *inout, int n);
+int smc_comm_allreduce_max_f64(smc_ctx *ctx, double *inout, int n);
+int smc_comm_allreduce_sum_i64(smc_ctx *ctx, int64_t *inout, int n);
+int smc_comm_allgather_f64(smc_ctx *ctx, const double *in, int n, double *out /* world*n */);
+int smc_comm_allgather_i64(smc_ctx *ctx, const int64_t *in, int n, int64_t *out /* world*n */);
+int smc_comm_barrier(smc_ctx *ctx);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* HIP-event timing of the kernels launched on the context's stream: smc_timing_reset clears the
+ * accumulators; smc_timing_get returns, for kernel class `which`, launches and total milliseconds
+ * measured with hipEvents recorded on that stream around each launch (enabled by smc_timing_enable). */
+#define SMC_T_LOGLIK 0
+#define SMC_T_MH 1
+#define SMC_T_ESS 2
+#define SMC_T_RESAMPLE 3
+#define SMC_T_MOMENTS 4
+#define SMC_T_MAX 5
+#define SMC_T_COUNT 6
+int smc_timing_enable(smc_ctx *ctx, int enable);
+int smc_timing_reset(smc_ctx *ctx);
+int smc_timing_get(smc_ctx *ctx, int which, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMC_HIP_H */

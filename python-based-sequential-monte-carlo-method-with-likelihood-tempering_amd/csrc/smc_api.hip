@@ -1,0 +1,784 @@
+// smc_api.hip -- host side of the C ABI declared in include/smc_hip.h: context, device memory,
+// stream, stage orchestration, RCCL collectives and HIP-event timing.  No torch, no Python types.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "smc_internal.h"
+#include "stage_kernels.h"
+
+using namespace smc;
+
+static thread_local std::string g_err;
+
+#define HIPC(ctx, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            char buf_[512];                                                                               \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,  \
+                     __LINE__);                                                                           \
+            if (ctx)                                                                                      \
+                (ctx)->err = buf_;                                                                        \
+            else                                                                                          \
+                g_err = buf_;                                                                             \
+            return 1;                                                                                     \
+        }                                                                                                 \
+    } while (0)
+
+#define NCCLC(ctx, call)                                                                                  \
+    do {                                                                                                  \
+        ncclResult_t e_ = (call);                                                                         \
+        if (e_ != ncclSuccess) {                                                                          \
+            char buf_[512];                                                                               \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(e_), __FILE__, \
+                     __LINE__);                                                                           \
+            if (ctx)                                                                                      \
+                (ctx)->err = buf_;                                                                        \
+            else                                                                                          \
+                g_err = buf_;                                                                             \
+            return 1;                                                                                     \
+        }                                                                                                 \
+    } while (0)
+
+static int fail(smc_ctx *ctx, const char *msg) {
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_err = msg;
+    return 1;
+}
+
+// ---- timing ---------------------------------------------------------------------------------
+namespace smc {
+ScopedTimer::ScopedTimer(smc_ctx *ctx, int which) : c(ctx), on(ctx->timing != 0) {
+    if (!on) return;
+    if (!c->ev_free.empty()) {
+        ep = c->ev_free.back();
+        c->ev_free.pop_back();
+    } else {
+        (void)hipEventCreate(&ep.a);
+        (void)hipEventCreate(&ep.b);
+    }
+    ep.which = which;
+    (void)hipEventRecord(ep.a, c->stream);
+}
+ScopedTimer::~ScopedTimer() {
+    if (!on) return;
+    (void)hipEventRecord(ep.b, c->stream);
+    c->ev_used.push_back(ep);
+}
+}  // namespace smc
+
+static void timing_collect(smc_ctx *c) {
+    for (auto &ep : c->ev_used) {
+        (void)hipEventSynchronize(ep.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            c->t_ms[ep.which] += ms;
+            c->t_launches[ep.which] += 1;
+        }
+        c->ev_free.push_back(ep);
+    }
+    c->ev_used.clear();
+}
+
+extern "C" {
+
+int smc_abi_version(void) { return SMC_ABI_VERSION; }
+
+const char *smc_last_error(const smc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int dim) {
+    if (!out) return fail(nullptr, "smc_create: out is NULL");
+    *out = nullptr;
+    if (n_local <= 0 || n_global < n_local) return fail(nullptr, "smc_create: need 0 < n_local <= n_global");
+    if (n_global >= (int64_t)1 << 31) return fail(nullptr, "smc_create: n_global must be < 2^31");
+    if (dim < 1 || dim > SMC_MAX_DIM) return fail(nullptr, "smc_create: dim out of range");
+    int ndev = 0;
+    HIPC((smc_ctx *)nullptr, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(nullptr, "smc_create: no such HIP device");
+    HIPC((smc_ctx *)nullptr, hipSetDevice(device));
+    smc_ctx *c = new (std::nothrow) smc_ctx();
+    if (!c) return fail(nullptr, "smc_create: out of host memory");
+    c->device = device;
+    c->dim = dim;
+    c->n_local = n_local;
+    c->n_global = n_global;
+#define CK(call)                                   \
+    do {                                           \
+        hipError_t e_ = (call);                    \
+        if (e_ != hipSuccess) {                    \
+            g_err = std::string(#call) + ": " + hipGetErrorString(e_); \
+            smc_destroy(c);                        \
+            return 1;                              \
+        }                                          \
+    } while (0)
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t nb = (size_t)n_local * sizeof(double);
+    for (int s = 0; s < 2; ++s) {
+        CK(hipMalloc(&c->set[s].theta, nb * dim));
+        CK(hipMalloc(&c->set[s].lk, nb));
+        CK(hipMemsetAsync(c->set[s].theta, 0, nb * dim, c->stream));
+        CK(hipMemsetAsync(c->set[s].lk, 0, nb, c->stream));
+        c->set[s].stride = n_local;
+    }
+    CK(hipMalloc(&c->r_ac, (size_t)n_local));
+    CK(hipMemsetAsync(c->r_ac, 0, (size_t)n_local, c->stream));
+    CK(hipMalloc(&c->d_counters, sizeof(SweepCounters)));
+    CK(hipHostMalloc(&c->h_counters, sizeof(SweepCounters)));
+    CK(hipMalloc(&c->d_noise, nb * (dim + 1)));
+    c->d_rr = c->d_noise + (size_t)n_local * dim;
+    CK(hipMalloc(&c->d_stage, nb * dim));
+    c->partials_cap = 2048 * 64;
+    CK(hipMalloc(&c->d_partials, (size_t)c->partials_cap * sizeof(double)));
+    CK(hipMalloc(&c->d_small, 4096 * sizeof(double)));
+    CK(hipHostMalloc(&c->h_small, 4096 * sizeof(double)));
+    c->n_tiles = (n_local + kScanTile - 1) / kScanTile;
+    CK(hipMalloc(&c->d_oscan, (size_t)n_local * sizeof(int32_t)));
+    CK(hipMalloc(&c->d_blk_r, (size_t)(c->n_tiles + 1) * sizeof(double)));
+    CK(hipMalloc(&c->d_blk_c, (size_t)(c->n_tiles + 1) * sizeof(int64_t)));
+    CK(hipStreamSynchronize(c->stream));
+#undef CK
+    *out = c;
+    return 0;
+}
+
+void smc_destroy(smc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->nccl_comm) ncclCommDestroy((ncclComm_t)c->nccl_comm);
+    for (auto &ep : c->ev_used) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    for (auto &ep : c->ev_free) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    for (int s = 0; s < 2; ++s) {
+        (void)hipFree(c->set[s].theta);
+        (void)hipFree(c->set[s].lk);
+    }
+    (void)hipFree(c->r_ac);
+    (void)hipFree(c->d_t);
+    (void)hipFree(c->d_P);
+    (void)hipFree(c->d_S0);
+    (void)hipFree(c->d_counters);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    (void)hipFree(c->d_noise);
+    (void)hipFree(c->d_stage);
+    (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_small);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    (void)hipFree(c->d_oscan);
+    (void)hipFree(c->d_blk_r);
+    (void)hipFree(c->d_blk_c);
+    (void)hipFree(c->d_sendbuf);
+    (void)hipFree(c->dbg_prop);
+    (void)hipFree(c->dbg_lk2);
+    (void)hipFree(c->dbg_p0);
+    (void)hipFree(c->dbg_r);
+    (void)hipFree(c->d_hb_theta);
+    (void)hipFree(c->d_hb_lk);
+    (void)hipFree(c->d_hb_pred);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int smc_synchronize(smc_ctx *c) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smc_device_info(smc_ctx *c, char *name, int name_len, char *arch, int arch_len, int *cu_count) {
+    if (!c) return fail(nullptr, "NULL context");
+    hipDeviceProp_t p;
+    HIPC(c, hipGetDeviceProperties(&p, c->device));
+    if (name && name_len > 0) snprintf(name, name_len, "%s", p.name);
+    if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    return 0;
+}
+
+// ---- model + prior ---------------------------------------------------------------------------
+int smc_set_model_mm(smc_ctx *c, const double *t, const double *P_obs, const double *S0, int n_ex, int n_t,
+                     int est_sigma, double sigma_fixed, double rtol, double atol) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (c->dim != 3) return fail(c, "Michaelis-Menten model needs dim == 3 (Vmax, Km, sigma)");
+    if (n_ex < 1 || n_ex > kMaxEx || n_t < 1 || n_t > kMaxNt) return fail(c, "n_ex must be 1..16 and n_t 1..256");
+    for (int e = 0; e < n_ex; ++e)
+        for (int i = 1; i < n_t; ++i)
+            if (!(t[e * n_t + i] > t[e * n_t + i - 1])) return fail(c, "t must be strictly increasing (ivp.py:606-609)");
+    HIPC(c, hipSetDevice(c->device));
+    (void)hipFree(c->d_t);
+    (void)hipFree(c->d_P);
+    (void)hipFree(c->d_S0);
+    c->d_t = c->d_P = c->d_S0 = nullptr;
+    const size_t nb = (size_t)n_ex * n_t * sizeof(double);
+    HIPC(c, hipMalloc(&c->d_t, nb));
+    HIPC(c, hipMalloc(&c->d_P, nb));
+    HIPC(c, hipMalloc(&c->d_S0, n_ex * sizeof(double)));
+    HIPC(c, hipMemcpyAsync(c->d_t, t, nb, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->d_P, P_obs, nb, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->d_S0, S0, n_ex * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->mm.t = c->d_t;
+    c->mm.P_obs = c->d_P;
+    c->mm.S0 = c->d_S0;
+    c->mm.n_ex = n_ex;
+    c->mm.n_t = n_t;
+    c->mm.est_sigma = est_sigma;
+    c->mm.sigma_fixed = sigma_fixed;
+    c->mm.rtol = rtol;
+    c->mm.atol = atol;
+    c->have_model = true;
+    return 0;
+}
+
+int smc_set_prior(smc_ctx *c, const int *kind, const double *a, const double *b, int dim) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (dim != c->dim) return fail(c, "smc_set_prior: dim mismatch");
+    for (int i = 0; i < dim; ++i) {
+        if (kind[i] != SMC_PRIOR_UNIFORM && kind[i] != SMC_PRIOR_NORMAL) return fail(c, "Unknown prior kind");
+        c->prior.kind[i] = kind[i];
+        c->prior.a[i] = a[i];
+        c->prior.b[i] = b[i];
+    }
+    c->prior.d = dim;
+    c->have_prior = true;
+    return 0;
+}
+
+// ---- particle movement -------------------------------------------------------------------------
+static int check_set(smc_ctx *c, int set, int64_t n) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (set != SMC_SET_PRED && set != SMC_SET_FILT) return fail(c, "bad particle set id");
+    if (n < 0 || n > c->n_local) return fail(c, "n exceeds the context capacity");
+    return 0;
+}
+
+int smc_upload_particles(smc_ctx *c, int set, const double *aos, int64_t n) {
+    if (check_set(c, set, n)) return 1;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(c->d_stage, aos, (size_t)n * c->dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_aos_to_soa(c, c->d_stage, c->set[set].theta, n, c->dim, c->set[set].stride);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smc_download_particles(smc_ctx *c, int set, double *aos, int64_t n) {
+    if (check_set(c, set, n)) return 1;
+    HIPC(c, hipSetDevice(c->device));
+    launch_soa_to_aos(c, c->set[set].theta, c->d_stage, n, c->dim, c->set[set].stride);
+    HIPC(c, hipMemcpyAsync(aos, c->d_stage, (size_t)n * c->dim * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smc_upload_lk(smc_ctx *c, int set, const double *lk, int64_t n) {
+    if (check_set(c, set, n)) return 1;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(c->set[set].lk, lk, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smc_download_lk(smc_ctx *c, int set, double *lk, int64_t n) {
+    if (check_set(c, set, n)) return 1;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(lk, c->set[set].lk, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smc_download_accept_flags(smc_ctx *c, uint8_t *flags, int64_t n) {
+    if (check_set(c, SMC_SET_FILT, n)) return 1;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemcpyAsync(flags, c->r_ac, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int smc_reset_accept_flags(smc_ctx *c) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemsetAsync(c->r_ac, 0, (size_t)c->n_local, c->stream));
+    return 0;
+}
+int smc_commit_filt_to_pred(smc_ctx *c) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t nb = (size_t)c->n_local * sizeof(double);
+    HIPC(c, hipMemcpyAsync(c->set[SMC_SET_PRED].theta, c->set[SMC_SET_FILT].theta, nb * c->dim,
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->set[SMC_SET_PRED].lk, c->set[SMC_SET_FILT].lk, nb, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int smc_sample_prior_device(smc_ctx *c, uint64_t seed, int64_t global_offset) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!c->have_prior) return fail(c, "smc_set_prior has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    launch_sample_prior(c, seed, global_offset);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// ---- sweeps --------------------------------------------------------------------------------------
+static int counters_begin(smc_ctx *c) {
+    HIPC(c, hipMemsetAsync(c->d_counters, 0, sizeof(SweepCounters), c->stream));
+    return 0;
+}
+static int counters_end(smc_ctx *c) {
+    HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(SweepCounters), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smc_loglik(smc_ctx *c, int set, int64_t *n_failed, int64_t *rk_attempts) {
+    if (check_set(c, set, 0)) return 1;
+    if (!c->have_model) return fail(c, "smc_set_model_mm has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    if (counters_begin(c)) return 1;
+    {
+        ScopedTimer tm(c, SMC_T_LOGLIK);
+        launch_mm_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk, nullptr);
+    }
+    HIPC(c, hipGetLastError());
+    if (counters_end(c)) return 1;
+    if (n_failed) *n_failed = (int64_t)c->h_counters->n_failed;
+    if (rk_attempts) *rk_attempts = (int64_t)c->h_counters->rk_attempts;
+    return 0;
+}
+
+int smc_mm_loglik_host(smc_ctx *c, const double *particle, int64_t n, double *lk, double *pred, int64_t *n_failed,
+                       int64_t *rk_attempts) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!c->have_model) return fail(c, "smc_set_model_mm has not been called");
+    if (n < 0) return fail(c, "n < 0");
+    HIPC(c, hipSetDevice(c->device));
+    if (n_failed) *n_failed = 0;
+    if (rk_attempts) *rk_attempts = 0;
+    if (n == 0) return 0;
+    if (n > c->hb_cap) {
+        (void)hipFree(c->d_hb_theta);
+        (void)hipFree(c->d_hb_lk);
+        c->d_hb_theta = c->d_hb_lk = nullptr;
+        c->hb_cap = 0;
+        HIPC(c, hipMalloc(&c->d_hb_theta, (size_t)n * 3 * sizeof(double) * 2));  // AoS staging + SoA
+        HIPC(c, hipMalloc(&c->d_hb_lk, (size_t)n * sizeof(double)));
+        c->hb_cap = n;
+    }
+    const size_t per = (size_t)c->mm.n_ex * c->mm.n_t;
+    if (pred && n > c->hb_pred_cap) {
+        (void)hipFree(c->d_hb_pred);
+        c->d_hb_pred = nullptr;
+        c->hb_pred_cap = 0;
+        HIPC(c, hipMalloc(&c->d_hb_pred, (size_t)n * per * sizeof(double)));
+        c->hb_pred_cap = n;
+    }
+    double *aos = c->d_hb_theta, *soa = c->d_hb_theta + (size_t)c->hb_cap * 3;
+    HIPC(c, hipMemcpyAsync(aos, particle, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_aos_to_soa(c, aos, soa, n, 3, n);
+    if (counters_begin(c)) return 1;
+    {
+        ScopedTimer tm(c, SMC_T_LOGLIK);
+        launch_mm_loglik(c, soa, n, n, c->d_hb_lk, pred ? c->d_hb_pred : nullptr);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(lk, c->d_hb_lk, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pred)
+        HIPC(c, hipMemcpyAsync(pred, c->d_hb_pred, (size_t)n * per * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (counters_end(c)) return 1;
+    if (n_failed) *n_failed = (int64_t)c->h_counters->n_failed;
+    if (rk_attempts) *rk_attempts = (int64_t)c->h_counters->rk_attempts;
+    return 0;
+}
+
+static int fetch_small(smc_ctx *c, int n) {
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smc_max_lk_local(smc_ctx *c, double *max_lk) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_MAX);
+        launch_max(c, c->set[SMC_SET_PRED].lk, c->n_local, c->d_small);
+    }
+    HIPC(c, hipGetLastError());
+    if (fetch_small(c, 1)) return 1;
+    *max_lk = c->h_small[0];
+    return 0;
+}
+
+int smc_ess_partials(smc_ctx *c, double max_lk, const double *gm, int n_cand, double *sum_w, double *sum_w2) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (n_cand < 1 || n_cand > SMC_MAX_ESS_CAND) return fail(c, "n_cand out of range");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_ESS);
+        launch_ess(c, c->set[SMC_SET_PRED].lk, c->n_local, max_lk, gm, n_cand, c->d_small);
+    }
+    HIPC(c, hipGetLastError());
+    if (fetch_small(c, 2 * ess_padded_k(n_cand))) return 1;
+    for (int k = 0; k < n_cand; ++k) {
+        sum_w[k] = c->h_small[2 * k];
+        sum_w2[k] = c->h_small[2 * k + 1];
+    }
+    return 0;
+}
+
+// ---- resampling ------------------------------------------------------------------------------------
+int smc_resample_phase1(smc_ctx *c, double max_lk, double gm, double sum_weight_global, double *residual_sum_local,
+                        int64_t *count_sum_local) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_RESAMPLE);
+        launch_resample_phase1(c, max_lk, gm, sum_weight_global);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_blk_r + c->n_tiles, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_small + 1, c->d_blk_c + c->n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    *residual_sum_local = c->h_small[0];
+    int64_t cs;
+    memcpy(&cs, c->h_small + 1, sizeof cs);
+    *count_sum_local = cs;
+    return 0;
+}
+
+int smc_resample_phase2(smc_ctx *c, double max_lk, double gm, double sum_weight_global, double residual_prefix,
+                        double wrand, int64_t *offspring_local) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_RESAMPLE);
+        launch_resample_phase2(c, max_lk, gm, sum_weight_global, residual_prefix, wrand);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_blk_c + c->n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    int64_t o;
+    memcpy(&o, c->h_small, sizeof o);
+    *offspring_local = o;
+    return 0;
+}
+
+int smc_download_offspring(smc_ctx *c, int64_t *p_is, int64_t n) {
+    if (check_set(c, SMC_SET_PRED, n)) return 1;
+    HIPC(c, hipSetDevice(c->device));
+    int64_t *d_tmp = nullptr;
+    HIPC(c, hipMalloc(&d_tmp, (size_t)c->n_local * sizeof(int64_t)));
+    launch_offspring_from_scan(c, d_tmp);
+    hipError_t e = hipMemcpyAsync(p_is, d_tmp, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_tmp);
+    HIPC(c, e);
+    return 0;
+}
+
+static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+static inline int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+
+int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *offspring_all, int first_step) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    const int W = c->world, R = c->rank, d = c->dim;
+    const int64_t nl = c->n_local;
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    int64_t total = 0;
+    for (int q = 0; q < W; ++q) {
+        if (out_base_all[q] != total) return fail(c, "out_base_all must be the exclusive prefix of offspring_all");
+        total += offspring_all[q];
+    }
+    if (total > c->n_global)
+        return fail(c, "resampling produced more offspring than particles (the reference raises IndexError, "
+                       "Micmem_SMC_main.py:180)");
+    const int64_t my_base = out_base_all[R], my_cnt = offspring_all[R];
+    ScopedTimer tm(c, SMC_T_RESAMPLE);
+
+    // how much leaves this rank
+    int64_t remote = 0;
+    for (int q = 0; q < W; ++q) {
+        if (q == R) continue;
+        const int64_t lo = imax(my_base, q * nl), hi = imin(my_base + my_cnt, (q + 1) * nl);
+        if (hi > lo) remote += hi - lo;
+    }
+    if (remote > c->sendbuf_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_sendbuf);
+        c->d_sendbuf = nullptr;
+        c->sendbuf_cap = 0;
+        HIPC(c, hipMalloc(&c->d_sendbuf, (size_t)remote * (d + 1) * sizeof(double)));
+        c->sendbuf_cap = remote;
+    }
+    if (W > 1 && !c->nccl_comm) return fail(c, "world > 1 but smc_comm_init has not been called");
+
+    // 1. gather: own slots straight into p_filt / lk1, remote slots into the send staging
+    int64_t soff = 0;
+    std::vector<int64_t> send_off(W, 0), send_cnt(W, 0);
+    for (int q = 0; q < W; ++q) {
+        const int64_t lo = imax(my_base, q * nl), hi = imin(my_base + my_cnt, (q + 1) * nl);
+        if (hi <= lo) continue;
+        if (q == R) {
+            launch_resample_gather(c, lo - my_base, hi - my_base, F.theta, F.stride, F.lk, lo - R * nl);
+        } else {
+            const int64_t cnt = hi - lo;
+            double *blk = c->d_sendbuf + (size_t)soff * (d + 1);  // [component][cnt], component d = lk
+            launch_resample_gather(c, lo - my_base, hi - my_base, blk, cnt, blk + (size_t)d * cnt, 0);
+            send_off[q] = soff;
+            send_cnt[q] = cnt;
+            soff += cnt;
+        }
+    }
+    // 2. rows nobody writes (total < N): what the reference's persistent buffers hold
+    {
+        const int64_t lo = imax(total - R * nl, 0);
+        if (lo < nl) launch_resample_stale(c, lo, nl, first_step);
+    }
+    HIPC(c, hipGetLastError());
+    // 3. exchange: per peer and component one send / one recv, received straight into the SoA rows
+    if (W > 1) {
+        ncclComm_t comm = (ncclComm_t)c->nccl_comm;
+        NCCLC(c, ncclGroupStart());
+        for (int q = 0; q < W; ++q) {
+            if (q == R) continue;
+            if (send_cnt[q] > 0) {
+                double *blk = c->d_sendbuf + (size_t)send_off[q] * (d + 1);
+                for (int k = 0; k <= d; ++k)
+                    NCCLC(c, ncclSend(blk + (size_t)k * send_cnt[q], (size_t)send_cnt[q], ncclDouble, q, comm, c->stream));
+            }
+            const int64_t lo = imax(out_base_all[q], R * nl), hi = imin(out_base_all[q] + offspring_all[q], (R + 1) * nl);
+            if (hi > lo) {
+                const int64_t off = lo - R * nl, cnt = hi - lo;
+                for (int k = 0; k < d; ++k)
+                    NCCLC(c, ncclRecv(F.theta + (size_t)k * F.stride + off, (size_t)cnt, ncclDouble, q, comm, c->stream));
+                NCCLC(c, ncclRecv(F.lk + off, (size_t)cnt, ncclDouble, q, comm, c->stream));
+            }
+        }
+        NCCLC(c, ncclGroupEnd());
+    }
+    return 0;
+}
+
+// ---- moments -----------------------------------------------------------------------------------------
+int smc_moment_sums_local(smc_ctx *c, double *sums) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_MOMENTS);
+        launch_moment_sums(c, c->d_small);
+    }
+    HIPC(c, hipGetLastError());
+    if (fetch_small(c, c->dim)) return 1;
+    for (int i = 0; i < c->dim; ++i) sums[i] = c->h_small[i];
+    return 0;
+}
+int smc_moment_centered_local(smc_ctx *c, const double *mean, double *centered) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_MOMENTS);
+        launch_moment_centered(c, mean, c->d_small);
+    }
+    HIPC(c, hipGetLastError());
+    const int d = c->dim;
+    if (fetch_small(c, d * (d + 1) / 2)) return 1;
+    int k = 0;
+    for (int a = 0; a < d; ++a)
+        for (int b = a; b < d; ++b) {
+            centered[a * d + b] = c->h_small[k];
+            centered[b * d + a] = c->h_small[k];
+            ++k;
+        }
+    return 0;
+}
+
+// ---- MH ------------------------------------------------------------------------------------------------
+static int mh_finish(smc_ctx *c, int64_t *accepted_now, int64_t *accepted_ever, int64_t *n_failed, int64_t *rk_attempts) {
+    HIPC(c, hipGetLastError());
+    if (counters_end(c)) return 1;
+    if (accepted_now) *accepted_now = (int64_t)c->h_counters->accepted_now;
+    if (accepted_ever) *accepted_ever = (int64_t)c->h_counters->accepted_ever;
+    if (n_failed) *n_failed = (int64_t)c->h_counters->n_failed;
+    if (rk_attempts) *rk_attempts = (int64_t)c->h_counters->rk_attempts;
+    return 0;
+}
+
+int smc_mh_step_host_rng(smc_ctx *c, double gamma, double mhstep_ratio, const double *noise, const double *rr, int64_t n,
+                         int64_t *accepted_now, int64_t *accepted_ever, int64_t *n_failed, int64_t *rk_attempts) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
+    if (n != c->n_local) return fail(c, "smc_mh_step_host_rng: n must equal the context's n_local");
+    HIPC(c, hipSetDevice(c->device));
+    const int d = c->dim;
+    HIPC(c, hipMemcpyAsync(c->d_stage, noise, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    launch_aos_to_soa(c, c->d_stage, c->d_noise, n, d, n);
+    HIPC(c, hipMemcpyAsync(c->d_rr, rr, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (counters_begin(c)) return 1;
+    MHParams mh{};
+    mh.gamma = gamma;
+    mh.ratio = mhstep_ratio;
+    mh.noise = c->d_noise;
+    mh.rr = c->d_rr;
+    mh.device_rng = 0;
+    {
+        ScopedTimer tm(c, SMC_T_MH);
+        launch_mm_mh(c, n, mh);
+    }
+    return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
+}
+
+int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const double *transform, uint64_t seed,
+                           uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
+                           int64_t *n_failed, int64_t *rk_attempts) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
+    HIPC(c, hipSetDevice(c->device));
+    if (counters_begin(c)) return 1;
+    MHParams mh{};
+    mh.gamma = gamma;
+    mh.ratio = mhstep_ratio;
+    mh.device_rng = 1;
+    mh.seed = seed;
+    mh.stream = stream;
+    mh.global_offset = global_offset;
+    for (int i = 0; i < c->dim * c->dim; ++i) mh.transform[i] = transform[i];
+    {
+        ScopedTimer tm(c, SMC_T_MH);
+        launch_mm_mh(c, c->n_local, mh);
+    }
+    return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
+}
+
+int smc_set_debug_capture(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    if (enable && !c->dbg_prop) {
+        const size_t n = (size_t)c->n_local;
+        HIPC(c, hipMalloc(&c->dbg_prop, n * c->dim * sizeof(double)));
+        HIPC(c, hipMalloc(&c->dbg_lk2, n * sizeof(double)));
+        HIPC(c, hipMalloc(&c->dbg_p0, n));
+        HIPC(c, hipMalloc(&c->dbg_r, n));
+    }
+    c->debug_capture = enable;
+    return 0;
+}
+int smc_download_debug_proposals(smc_ctx *c, double *aos, double *lk2, uint8_t *p0, uint8_t *r, int64_t n) {
+    if (check_set(c, SMC_SET_FILT, n)) return 1;
+    if (!c->dbg_prop) return fail(c, "debug capture is not enabled");
+    HIPC(c, hipSetDevice(c->device));
+    launch_soa_to_aos(c, c->dbg_prop, c->d_stage, n, c->dim, c->n_local);
+    HIPC(c, hipMemcpyAsync(aos, c->d_stage, (size_t)n * c->dim * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(lk2, c->dbg_lk2, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(p0, c->dbg_p0, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(r, c->dbg_r, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- collectives -----------------------------------------------------------------------------------------
+int smc_comm_get_unique_id(uint8_t id[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    NCCLC((smc_ctx *)nullptr, ncclGetUniqueId(&u));
+    memcpy(id, &u, 128);
+    return 0;
+}
+int smc_comm_init(smc_ctx *c, const uint8_t id[128], int rank, int world) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (world < 1 || world > SMC_MAX_RANKS || rank < 0 || rank >= world) return fail(c, "bad rank/world");
+    if (c->n_global != c->n_local * world) return fail(c, "n_global must equal world * n_local");
+    HIPC(c, hipSetDevice(c->device));
+    c->rank = rank;
+    c->world = world;
+    if (world == 1) return 0;
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclComm_t comm;
+    NCCLC(c, ncclCommInitRank(&comm, world, u, rank));
+    c->nccl_comm = comm;
+    return 0;
+}
+
+}  // extern "C"
+template <typename T>
+static int allreduce_impl(smc_ctx *c, T *inout, int n, ncclDataType_t dt, ncclRedOp_t op) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (n < 0 || (size_t)n * sizeof(T) > 4096 * sizeof(double)) return fail(c, "collective payload too large");
+    if (c->world == 1 || n == 0) return 0;
+    HIPC(c, hipSetDevice(c->device));
+    memcpy(c->h_small, inout, (size_t)n * sizeof(T));
+    HIPC(c, hipMemcpyAsync(c->d_small, c->h_small, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    NCCLC(c, ncclAllReduce(c->d_small, c->d_small, (size_t)n, dt, op, (ncclComm_t)c->nccl_comm, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    memcpy(inout, c->h_small, (size_t)n * sizeof(T));
+    return 0;
+}
+extern "C" {
+int smc_comm_allreduce_sum_f64(smc_ctx *c, double *inout, int n) { return allreduce_impl(c, inout, n, ncclDouble, ncclSum); }
+int smc_comm_allreduce_max_f64(smc_ctx *c, double *inout, int n) { return allreduce_impl(c, inout, n, ncclDouble, ncclMax); }
+int smc_comm_allreduce_sum_i64(smc_ctx *c, int64_t *inout, int n) { return allreduce_impl(c, inout, n, ncclInt64, ncclSum); }
+
+}  // extern "C"
+template <typename T>
+static int allgather_impl(smc_ctx *c, const T *in, int n, T *out, ncclDataType_t dt) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (n < 0 || (size_t)n * c->world * sizeof(T) > 2048 * sizeof(double)) return fail(c, "collective payload too large");
+    if (c->world == 1) {
+        memcpy(out, in, (size_t)n * sizeof(T));
+        return 0;
+    }
+    HIPC(c, hipSetDevice(c->device));
+    T *dsend = (T *)c->d_small, *drecv = (T *)(c->d_small + 2048);
+    memcpy(c->h_small, in, (size_t)n * sizeof(T));
+    HIPC(c, hipMemcpyAsync(dsend, c->h_small, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    NCCLC(c, ncclAllGather(dsend, drecv, (size_t)n, dt, (ncclComm_t)c->nccl_comm, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_small, drecv, (size_t)n * c->world * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    memcpy(out, c->h_small, (size_t)n * c->world * sizeof(T));
+    return 0;
+}
+extern "C" {
+int smc_comm_allgather_f64(smc_ctx *c, const double *in, int n, double *out) { return allgather_impl(c, in, n, out, ncclDouble); }
+int smc_comm_allgather_i64(smc_ctx *c, const int64_t *in, int n, int64_t *out) { return allgather_impl(c, in, n, out, ncclInt64); }
+int smc_comm_barrier(smc_ctx *c) {
+    double x = 0.0;
+    return smc_comm_allreduce_sum_f64(c, &x, 1);
+}
+
+// ---- timing ----------------------------------------------------------------------------------------------
+int smc_timing_enable(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    c->timing = enable;
+    return 0;
+}
+int smc_timing_reset(smc_ctx *c) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    timing_collect(c);
+    for (int i = 0; i < SMC_T_COUNT; ++i) {
+        c->t_launches[i] = 0;
+        c->t_ms[i] = 0.0;
+    }
+    return 0;
+}
+int smc_timing_get(smc_ctx *c, int which, int64_t *launches, double *total_ms) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (which < 0 || which >= SMC_T_COUNT) return fail(c, "bad timing class");
+    HIPC(c, hipSetDevice(c->device));
+    timing_collect(c);
+    if (launches) *launches = c->t_launches[which];
+    if (total_ms) *total_ms = c->t_ms[which];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// smc_internal.h -- context layout and launch helpers shared by the translation units of
+// libsmc_hip.so.  Not part of the ABI (that is include/smc_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/smc_hip.h"
+
+namespace smc {
+
+constexpr int kWave = 64;            // gfx950 wavefront
+constexpr int kMaxEx = 16;           // experiments per data set (waves per sweep block)
+constexpr int kMaxNt = 256;          // data times per experiment
+constexpr int kScanBlock = 256;      // threads per block in the scan / reduction kernels
+constexpr int kScanItems = 4;        // consecutive items per thread in the resampling scans
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+struct MMModel {     // passed by value to the sweep kernel
+    const double *t;      // n_ex*n_t (device)
+    const double *P_obs;  // n_ex*n_t (device)
+    const double *S0;     // n_ex (device)
+    int n_ex, n_t, est_sigma;
+    double sigma_fixed, rtol, atol;
+};
+
+struct Prior {       // passed by value
+    int kind[SMC_MAX_DIM];
+    double a[SMC_MAX_DIM], b[SMC_MAX_DIM];
+    int d;
+};
+
+struct ParticleSet {  // SoA view: theta[c][i] = theta_base[c*stride + i]
+    double *theta;
+    double *lk;
+    int64_t stride;
+};
+
+struct MHParams {    // passed by value to the fused MH kernel
+    double gamma, ratio;
+    const double *noise;  // host-RNG mode: SoA d x n (device); nullptr in device-RNG mode
+    const double *rr;     // host-RNG mode: n uniforms (device)
+    double transform[SMC_MAX_DIM * SMC_MAX_DIM];  // device-RNG mode: z @ transform
+    uint64_t seed, stream;
+    int64_t global_offset;
+    int device_rng;
+};
+
+struct SweepCounters {  // device-side integer counters (order-independent atomics)
+    unsigned long long n_failed, rk_attempts, accepted_now, accepted_ever;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int which;
+};
+
+}  // namespace smc
+
+struct smc_ctx {
+    int device = 0;
+    int dim = 0;
+    int64_t n_local = 0, n_global = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // particle sets (SoA), lk arrays
+    smc::ParticleSet set[2]{};
+    uint8_t *r_ac = nullptr;
+
+    // model
+    bool have_model = false, have_prior = false;
+    smc::MMModel mm{};
+    double *d_t = nullptr, *d_P = nullptr, *d_S0 = nullptr;
+    smc::Prior prior{};
+
+    // scratch
+    smc::SweepCounters *d_counters = nullptr;
+    smc::SweepCounters *h_counters = nullptr;   // pinned
+    double *d_noise = nullptr, *d_rr = nullptr;  // host-RNG staging: (d+1) x n_local
+    double *d_stage = nullptr;                   // AoS staging for upload/download: n_local*d
+    double *d_partials = nullptr;                // reduction partials
+    int64_t partials_cap = 0;
+    double *d_small = nullptr, *h_small = nullptr;  // small results (device / pinned host), 4096 doubles
+    // resampling
+    int32_t *d_oscan = nullptr;      // inclusive offspring scan (n_local)
+    double *d_blk_r = nullptr;       // per tile: residual sums, then exclusive prefix
+    int64_t *d_blk_c = nullptr;      // per tile: integer sums, then exclusive prefix
+    int64_t n_tiles = 0;
+    double *d_sendbuf = nullptr;     // (d+1) x capacity staging for remote offspring
+    int64_t sendbuf_cap = 0;
+    // debug capture of the last MH proposals
+    int debug_capture = 0;
+    double *dbg_prop = nullptr, *dbg_lk2 = nullptr;
+    uint8_t *dbg_p0 = nullptr, *dbg_r = nullptr;
+    // host batch sweeps (drop-in sim_particle)
+    double *d_hb_theta = nullptr, *d_hb_lk = nullptr, *d_hb_pred = nullptr;
+    int64_t hb_cap = 0, hb_pred_cap = 0;
+
+    // comm
+    void *nccl_comm = nullptr;
+    int rank = 0, world = 1;
+
+    // timing
+    int timing = 0;
+    std::vector<smc::EventPair> ev_used;
+    std::vector<smc::EventPair> ev_free;
+    int64_t t_launches[SMC_T_COUNT]{};
+    double t_ms[SMC_T_COUNT]{};
+};
+
+namespace smc {
+
+// kernel launchers implemented in mm_kernels.hip
+void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred);
+void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
+
+struct ScopedTimer {
+    smc_ctx *c;
+    EventPair ep{};
+    bool on;
+    ScopedTimer(smc_ctx *ctx, int which);
+    ~ScopedTimer();
+};
+
+}  // namespace smc

@@ -1,0 +1,553 @@
+// stage_kernels.hip -- the HBM-bound stages around the sweep: AoS<->SoA transposes, max / tempered
+// weight sums (ESS), residual-systematic resampling (scan + binary-search gather), moments, device
+// prior draw.  gfx950 only.  All floating-point reductions use fixed shapes (per-block partials in a
+// fixed order + a single-block final pass), so results are reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include "philox.h"
+#include "smc_internal.h"
+#include "stage_kernels.h"
+
+namespace smc {
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (wave64: six shuffle steps, then one LDS hop across the waves)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(v, off);
+        v = (o > v || o != o) ? o : v;  // NaN-propagating like np.max
+    }
+    return v;
+}
+
+// block-wide sum for blockDim.x == kScanBlock (4 waves); result valid in thread 0
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T *lds /* >= 4 */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) lds[w] = v;
+    __syncthreads();
+    T r = lds[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r += lds[i];
+    return r;
+}
+
+// inclusive scan across the block of one value per thread (kScanBlock threads); returns inclusive
+// value, *total = block total.  Wave scan by shuffles, wave totals through LDS.
+template <typename T>
+__device__ __forceinline__ T block_inclusive_scan(T v, T *lds /* >= 4 */, T *total) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T o = __shfl_up(v, off);
+        if (l >= off) v += o;
+    }
+    __syncthreads();
+    if (l == 63) lds[w] = v;
+    __syncthreads();
+    T base = 0;
+    T tot = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+        if (i < w) base += lds[i];
+        tot += lds[i];
+    }
+    *total = tot;
+    return v + base;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transposes (AoS (n,d) <-> SoA d x stride)
+// ---------------------------------------------------------------------------------------------
+__global__ void aos_to_soa_kernel(const double *__restrict__ aos, double *__restrict__ soa, int64_t n, int d,
+                                  int64_t stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    const int64_t p = i / d;
+    const int c = (int)(i - p * d);
+    soa[c * stride + p] = aos[i];
+}
+__global__ void soa_to_aos_kernel(const double *__restrict__ soa, double *__restrict__ aos, int64_t n, int d,
+                                  int64_t stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    const int64_t p = i / d;
+    const int c = (int)(i - p * d);
+    aos[i] = soa[c * stride + p];
+}
+
+// ---------------------------------------------------------------------------------------------
+// device prior draw (replaces sample_prior in device-RNG mode)
+// ---------------------------------------------------------------------------------------------
+__global__ void sample_prior_kernel(Prior prior, double *__restrict__ theta, int64_t stride, int64_t n, uint64_t seed,
+                                    int64_t goff) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint64_t g = (uint64_t)(goff + p);
+    for (int c = 0; c < prior.d; ++c) {
+        const u32x4 r = philox_block(seed, g, 0xFFFFFFFF00000000ull | (uint64_t)c, 0);
+        double v;
+        if (prior.kind[c] == SMC_PRIOR_UNIFORM) {
+            v = prior.a[c] + (prior.b[c] - prior.a[c]) * u01_from(r.x, r.y);
+        } else {
+            const double u1 = 1.0 - u01_from(r.x, r.y), u2 = u01_from(r.z, r.w);
+            v = prior.a[c] + prior.b[c] * (sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+        }
+        theta[c * stride + p] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// max(lk)  (Micmem_SMC_main.py:116)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kScanBlock) max_partial_kernel(const double *__restrict__ lk, int64_t n,
+                                                                 double *__restrict__ partials) {
+    __shared__ double lds[4];
+    double m = -__longlong_as_double(0x7ff0000000000000LL);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = lk[i];
+        m = (v > m || v != v) ? v : m;
+    }
+    m = wave_max(m);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) lds[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int i = 1; i < 4; ++i) r = (lds[i] > r || lds[i] != lds[i]) ? lds[i] : r;
+        partials[blockIdx.x] = r;
+    }
+}
+__global__ void __launch_bounds__(kScanBlock) max_final_kernel(const double *__restrict__ partials, int np,
+                                                               double *__restrict__ out) {
+    __shared__ double lds[4];
+    double m = -__longlong_as_double(0x7ff0000000000000LL);
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        const double v = partials[i];
+        m = (v > m || v != v) ? v : m;
+    }
+    m = wave_max(m);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) lds[w] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = lds[0];
+        for (int i = 1; i < 4; ++i) r = (lds[i] > r || lds[i] != lds[i]) ? lds[i] : r;
+        out[0] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tempered weight sums for K candidate increments in ONE pass over lk (Micmem_SMC_main.py:118,
+// 124-134): 8 bytes of HBM per particle for all K candidates instead of ~6 NumPy passes each.
+// ---------------------------------------------------------------------------------------------
+struct EssCand {
+    double gm[SMC_MAX_ESS_CAND];
+    int k;
+};
+
+template <int K>
+__global__ void __launch_bounds__(kScanBlock) ess_partial_kernel(const double *__restrict__ lk, int64_t n, double max_lk,
+                                                                 EssCand cand, double *__restrict__ partials) {
+    __shared__ double lds[4];
+    double s1[K], s2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) s1[k] = s2[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = lk[i] - max_lk;  // d_lk (:118)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double w = exp(d * cand.gm[k]);  // :124
+            s1[k] += w;
+            s2[k] += w * w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double a = block_sum(s1[k], lds);
+        const double b = block_sum(s2[k], lds);
+        if (threadIdx.x == 0) {
+            partials[((size_t)blockIdx.x * K + k) * 2 + 0] = a;
+            partials[((size_t)blockIdx.x * K + k) * 2 + 1] = b;
+        }
+    }
+}
+// sums nvals interleaved values over np partial rows, in row order
+__global__ void __launch_bounds__(kScanBlock) sum_rows_final_kernel(const double *__restrict__ partials, int np,
+                                                                    int nvals, double *__restrict__ out) {
+    __shared__ double lds[4];
+    for (int v = 0; v < nvals; ++v) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < np; i += blockDim.x) s += partials[(size_t)i * nvals + v];
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) out[v] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// moments for np.cov(p_filt.T, bias=True)  (Micmem_SMC_main.py:212)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kScanBlock) moment_sum_kernel(const double *__restrict__ theta, int64_t stride,
+                                                                int64_t n, int d, double *__restrict__ partials) {
+    __shared__ double lds[4];
+    for (int c = 0; c < d; ++c) {
+        double s = 0.0;
+        const double *x = theta + c * stride;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+            s += x[i];
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * d + c] = s;
+    }
+}
+struct MeanArg {
+    double m[SMC_MAX_DIM];
+};
+__global__ void __launch_bounds__(kScanBlock) moment_centered_kernel(const double *__restrict__ theta, int64_t stride,
+                                                                     int64_t n, int d, MeanArg mean,
+                                                                     double *__restrict__ partials) {
+    __shared__ double lds[4];
+    double acc[SMC_MAX_DIM * (SMC_MAX_DIM + 1) / 2];
+    const int npair = d * (d + 1) / 2;
+    for (int k = 0; k < npair; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double x[SMC_MAX_DIM];
+        for (int c = 0; c < d; ++c) x[c] = theta[c * stride + i] - mean.m[c];
+        int k = 0;
+        for (int a = 0; a < d; ++a)
+            for (int b = a; b < d; ++b) acc[k++] += x[a] * x[b];
+    }
+    for (int k = 0; k < npair; ++k) {
+        const double s = block_sum(acc[k], lds);
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * npair + k] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// residual-systematic resampling (Micmem_SMC_main.py:147-184)
+// ---------------------------------------------------------------------------------------------
+// Tiles of kScanTile consecutive particles; a thread owns kScanItems consecutive ones.
+struct ResampleArgs {
+    double max_lk, gm, sum_w;  // w_i = exp((lk_i-max_lk)*gm)/sum_w          (:124,130)
+    double n_global, inv_np;   // p_is = trunc(w*N); residual = w - p_is*inv_Np (:147,150)
+    double wrand, base;        // wrand (:156); base = residual sum of all lower ranks
+    int first_rank;            // this rank holds global particle 0
+};
+
+__device__ __forceinline__ void resample_item(const ResampleArgs &a, double lk, double &resid, int64_t &cnt) {
+    const double w = exp((lk - a.max_lk) * a.gm) / a.sum_w;
+    const double c = trunc(w * a.n_global);
+    cnt = (int64_t)c;
+    resid = w - c * a.inv_np;
+}
+
+// phase 1: per tile sums of residuals and integer parts
+__global__ void __launch_bounds__(kScanBlock) resample_tile_sums_kernel(const double *__restrict__ lk, int64_t n,
+                                                                        ResampleArgs a, double *__restrict__ blk_r,
+                                                                        int64_t *__restrict__ blk_c) {
+    __shared__ double lds_d[4];
+    __shared__ int64_t lds_i[4];
+    const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+    double rs = 0.0;
+    int64_t cs = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        if (i < n) {
+            double r;
+            int64_t c;
+            resample_item(a, lk[i], r, c);
+            rs += r;
+            cs += c;
+        }
+    }
+    rs = block_sum(rs, lds_d);
+    cs = block_sum(cs, lds_i);
+    if (threadIdx.x == 0) {
+        blk_r[blockIdx.x] = rs;
+        blk_c[blockIdx.x] = cs;
+    }
+}
+
+// exclusive scan over the tile sums by ONE block (tiles <= ~10^4): every thread takes a contiguous
+// chunk.  In place: v[i] <- sum_{j<i} v[j]; v[nt] <- total (arrays hold nt+1 entries).
+template <typename T>
+__global__ void __launch_bounds__(kScanBlock) tile_exclusive_scan_kernel(T *__restrict__ v, int64_t nt) {
+    __shared__ T lds[4];
+    const int64_t chunk = (nt + kScanBlock - 1) / kScanBlock;
+    const int64_t lo = (int64_t)threadIdx.x * chunk, hi = (lo + chunk < nt) ? lo + chunk : nt;
+    T s = 0;
+    for (int64_t i = lo; i < hi; ++i) s += v[i];
+    T total;
+    const T incl = block_inclusive_scan(s, lds, &total);
+    T run = incl - s;
+    for (int64_t i = lo; i < hi; ++i) {
+        const T x = v[i];
+        v[i] = run;
+        run += x;
+    }
+    if (threadIdx.x == 0) v[nt] = total;
+}
+
+// number of systematic thresholds wrand + k/N (k >= 0) that are <= S   (:168-174)
+__device__ __forceinline__ int64_t thresholds_below(double S, const ResampleArgs &a) {
+    return (S >= a.wrand) ? (int64_t)floor((S - a.wrand) * a.n_global) + 1 : 0;
+}
+
+// phase 2: systematic offspring from the running residual sum, per-tile inclusive offspring scan.
+// Boundary values of the running sum are defined ONCE (tile start = base + tile prefix, thread start =
+// tile start + thread prefix) and used by both neighbours, so the extra offspring of a tile/rank add
+// up to exactly thresholds_below(end) - thresholds_below(start).
+__global__ void __launch_bounds__(kScanBlock)
+resample_offspring_kernel(const double *__restrict__ lk, int64_t n, ResampleArgs a, const double *__restrict__ blk_r_excl,
+                          int32_t *__restrict__ oscan, int64_t *__restrict__ blk_o) {
+    __shared__ double lds_d[4];
+    __shared__ int64_t lds_i[4];
+    __shared__ double thread_start[kScanBlock + 1];
+    const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+    double r[kScanItems];
+    int64_t c[kScanItems];
+    double rs = 0.0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        r[k] = 0.0;
+        c[k] = 0;
+        if (i < n) resample_item(a, lk[i], r[k], c[k]);
+        rs += r[k];
+    }
+    double tile_total;
+    const double incl = block_inclusive_scan(rs, lds_d, &tile_total);
+    const double tile_start = a.base + blk_r_excl[blockIdx.x];
+    const double tile_end = a.base + blk_r_excl[blockIdx.x + 1];
+    thread_start[threadIdx.x] = tile_start + (incl - rs);  // thread 0: incl == rs, i.e. exactly tile_start
+    if (threadIdx.x == 0) thread_start[kScanBlock] = tile_end;
+    __syncthreads();
+    double S = thread_start[threadIdx.x];
+    const double S_end = thread_start[threadIdx.x + 1];
+    int64_t m_prev = thresholds_below(S, a);
+    if (a.first_rank && blockIdx.x == 0 && threadIdx.x == 0) m_prev = 0;  // nothing precedes particle 0
+    int64_t o[kScanItems];
+    int64_t os = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        o[k] = 0;
+        if (i < n) {
+            // the last valid item of a thread ends exactly on the next thread's start value
+            // and the last particle of the rank ends on base + (this rank's residual total), the value
+            // the next rank starts from
+            const bool last = (k == kScanItems - 1);
+            S = (i + 1 >= n) ? tile_end : (last ? S_end : S + r[k]);
+            const int64_t m = thresholds_below(S, a);
+            int64_t extra = m - m_prev;
+            if (extra < 0) extra = 0;
+            m_prev = (m > m_prev) ? m : m_prev;
+            o[k] = c[k] + extra;
+            os += o[k];
+        }
+    }
+    int64_t tile_o;
+    const int64_t incl_o = block_inclusive_scan(os, lds_i, &tile_o);
+    int64_t run = incl_o - os;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        if (i < n) {
+            run += o[k];
+            oscan[i] = (int32_t)run;
+        }
+    }
+    if (threadIdx.x == 0) blk_o[blockIdx.x] = tile_o;
+}
+
+// add the tile prefixes: oscan becomes the inclusive offspring scan over this rank's block
+__global__ void __launch_bounds__(kScanBlock) resample_apply_prefix_kernel(int32_t *__restrict__ oscan, int64_t n,
+                                                                           const int64_t *__restrict__ blk_o_excl) {
+    const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+    const int32_t off = (int32_t)blk_o_excl[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        if (i < n) oscan[i] += off;
+    }
+}
+
+__global__ void offspring_from_scan_kernel(const int32_t *__restrict__ oscan, int64_t n, int64_t *__restrict__ p_is) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    p_is[i] = (int64_t)oscan[i] - (i ? (int64_t)oscan[i - 1] : 0);
+}
+
+// phase 3 (:178-184): output slot -> ancestor by binary search in the inclusive scan, then gather.
+// Local output slots [m_lo, m_hi) of this rank are written to dst (component c at dst + c*dst_stride
+// + dst_off + (m - m_lo)); component d is lk.
+__global__ void __launch_bounds__(256)
+resample_gather_kernel(const int32_t *__restrict__ oscan, int64_t n, const double *__restrict__ src_theta,
+                       int64_t src_stride, const double *__restrict__ src_lk, int d, int64_t m_lo, int64_t m_hi,
+                       double *__restrict__ dst_theta, int64_t dst_stride, double *__restrict__ dst_lk, int64_t dst_off) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t m = m_lo + k;
+    if (m >= m_hi) return;
+    // first j with oscan[j] > m
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)oscan[mid] > m)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    const int64_t j = lo;
+    for (int c = 0; c < d; ++c) dst_theta[c * dst_stride + dst_off + k] = src_theta[c * src_stride + j];
+    dst_lk[dst_off + k] = src_lk[j];
+}
+
+// rows the resampler did not write: what the reference's persistent p_filt / lk1 hold there
+__global__ void resample_stale_rows_kernel(const double *__restrict__ src_theta, int64_t src_stride,
+                                           const double *__restrict__ src_lk, int d, int64_t lo, int64_t hi,
+                                           int first_step, double *__restrict__ dst_theta, int64_t dst_stride,
+                                           double *__restrict__ dst_lk) {
+    const int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    for (int c = 0; c < d; ++c) dst_theta[c * dst_stride + i] = first_step ? 0.0 : src_theta[c * src_stride + i];
+    dst_lk[i] = first_step ? 0.0 : src_lk[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline int reduce_grid(int64_t n) {
+    int64_t g = (n + kScanBlock - 1) / kScanBlock;
+    if (g > 2048) g = 2048;  // 256 CUs x 8: grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+void launch_aos_to_soa(smc_ctx *c, const double *aos, double *soa, int64_t n, int d, int64_t stride) {
+    const int64_t tot = n * d;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, aos, soa, n, d,
+                       stride);
+}
+void launch_soa_to_aos(smc_ctx *c, const double *soa, double *aos, int64_t n, int d, int64_t stride) {
+    const int64_t tot = n * d;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, soa, aos, n, d,
+                       stride);
+}
+void launch_sample_prior(smc_ctx *c, uint64_t seed, int64_t goff) {
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    hipLaunchKernelGGL(sample_prior_kernel, dim3((unsigned)((c->n_local + 255) / 256)), dim3(256), 0, c->stream,
+                       c->prior, P.theta, P.stride, c->n_local, seed, goff);
+}
+void launch_max(smc_ctx *c, const double *lk, int64_t n, double *d_out) {
+    const int g = reduce_grid(n);
+    hipLaunchKernelGGL(max_partial_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, c->d_partials);
+    hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, d_out);
+}
+void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const double *gm, int k, double *d_out) {
+    EssCand cand{};
+    cand.k = k;
+    for (int i = 0; i < SMC_MAX_ESS_CAND; ++i) cand.gm[i] = (i < k) ? gm[i] : 0.0;
+    const int g = reduce_grid(n);
+    int K;
+    if (k <= 1) {
+        K = 1;
+        hipLaunchKernelGGL((ess_partial_kernel<1>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+                           c->d_partials);
+    } else if (k <= 4) {
+        K = 4;
+        hipLaunchKernelGGL((ess_partial_kernel<4>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+                           c->d_partials);
+    } else if (k <= 8) {
+        K = 8;
+        hipLaunchKernelGGL((ess_partial_kernel<8>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+                           c->d_partials);
+    } else {
+        K = 16;
+        hipLaunchKernelGGL((ess_partial_kernel<16>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+                           c->d_partials);
+    }
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, 2 * K, d_out);
+}
+int ess_padded_k(int k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 8 ? 8 : 16; }
+
+void launch_moment_sums(smc_ctx *c, double *d_out) {
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    const int g = reduce_grid(c->n_local);
+    hipLaunchKernelGGL(moment_sum_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, F.theta, F.stride, c->n_local,
+                       c->dim, c->d_partials);
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, c->dim, d_out);
+}
+void launch_moment_centered(smc_ctx *c, const double *mean, double *d_out) {
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    MeanArg m{};
+    for (int i = 0; i < c->dim; ++i) m.m[i] = mean[i];
+    const int g = reduce_grid(c->n_local);
+    const int npair = c->dim * (c->dim + 1) / 2;
+    hipLaunchKernelGGL(moment_centered_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, F.theta, F.stride, c->n_local,
+                       c->dim, m, c->d_partials);
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
+}
+
+static ResampleArgs make_args(smc_ctx *c, double max_lk, double gm, double sum_w, double wrand, double base) {
+    ResampleArgs a{};
+    a.max_lk = max_lk;
+    a.gm = gm;
+    a.sum_w = sum_w;
+    a.n_global = (double)c->n_global;
+    a.inv_np = 1.0 / (double)c->n_global;  // inv_Np = 1 / n_particle (Micmem_settings.py:17)
+    a.wrand = wrand;
+    a.base = base;
+    a.first_rank = (c->rank == 0);
+    return a;
+}
+void launch_resample_phase1(smc_ctx *c, double max_lk, double gm, double sum_w) {
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    const ResampleArgs a = make_args(c, max_lk, gm, sum_w, 0.0, 0.0);
+    const int64_t nt = c->n_tiles;
+    hipLaunchKernelGGL(resample_tile_sums_kernel, dim3((unsigned)nt), dim3(kScanBlock), 0, c->stream, P.lk, c->n_local, a,
+                       c->d_blk_r, c->d_blk_c);
+    hipLaunchKernelGGL((tile_exclusive_scan_kernel<double>), dim3(1), dim3(kScanBlock), 0, c->stream, c->d_blk_r, nt);
+    hipLaunchKernelGGL((tile_exclusive_scan_kernel<int64_t>), dim3(1), dim3(kScanBlock), 0, c->stream, c->d_blk_c, nt);
+}
+void launch_resample_phase2(smc_ctx *c, double max_lk, double gm, double sum_w, double base, double wrand) {
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    const ResampleArgs a = make_args(c, max_lk, gm, sum_w, wrand, base);
+    const int64_t nt = c->n_tiles;
+    // d_blk_c is reused for the per-tile offspring totals
+    hipLaunchKernelGGL(resample_offspring_kernel, dim3((unsigned)nt), dim3(kScanBlock), 0, c->stream, P.lk, c->n_local,
+                       a, c->d_blk_r, c->d_oscan, c->d_blk_c);
+    hipLaunchKernelGGL((tile_exclusive_scan_kernel<int64_t>), dim3(1), dim3(kScanBlock), 0, c->stream, c->d_blk_c, nt);
+    hipLaunchKernelGGL(resample_apply_prefix_kernel, dim3((unsigned)nt), dim3(kScanBlock), 0, c->stream, c->d_oscan,
+                       c->n_local, c->d_blk_c);
+}
+void launch_offspring_from_scan(smc_ctx *c, int64_t *d_out) {
+    hipLaunchKernelGGL(offspring_from_scan_kernel, dim3((unsigned)((c->n_local + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_oscan, c->n_local, d_out);
+}
+void launch_resample_gather(smc_ctx *c, int64_t m_lo, int64_t m_hi, double *dst_theta, int64_t dst_stride,
+                            double *dst_lk, int64_t dst_off) {
+    const int64_t cnt = m_hi - m_lo;
+    if (cnt <= 0) return;
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    hipLaunchKernelGGL(resample_gather_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->d_oscan,
+                       c->n_local, P.theta, P.stride, P.lk, c->dim, m_lo, m_hi, dst_theta, dst_stride, dst_lk, dst_off);
+}
+void launch_resample_stale(smc_ctx *c, int64_t lo, int64_t hi, int first_step) {
+    if (hi <= lo) return;
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    hipLaunchKernelGGL(resample_stale_rows_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, c->stream,
+                       P.theta, P.stride, P.lk, c->dim, lo, hi, first_step, F.theta, F.stride, F.lk);
+}
+
+}  // namespace smc

@@ -1,0 +1,282 @@
+"""The adaptive likelihood-tempering loop on the HIP engine.
+
+Host-side mirror of the reference's driver, which is inline script code
+(SMC_example/Micmem_SMC_main.py:95-262; SMC_methanation/SMC_methanation_main.py:194-418 is the same
+loop).  Stage by stage the control flow, the hyper-parameter names and the per-step log line are the
+reference's; the per-particle work of every stage runs in HIP kernels through the engine:
+
+  A2  engine.loglik                      sim_particle                     main:98,229
+  A3  engine.max_lk_local/ess_partials   weights, sum, ESS                main:116-134
+  A4  ess_search (this file)             geometric gamma back-off         main:111-113,120-144
+  A5  engine.resample_phase1..3          residual-systematic resampling   main:147-184
+  A6  engine.moment_*                    np.cov(p_filt.T, bias=True)      main:212-215
+  A7-A9 engine.mh_step_*                 proposal, prior mask, likelihood, accept/select  main:220-241
+  A10 run_smc (this file)                MH loop control                  main:187-208,243-252
+
+Two RNG modes:
+  rng="numpy"   parity mode: every random number is drawn by NumPy's global legacy generator in the
+                reference's order and uploaded - identical streams on identical seeds;
+  rng="device"  Philox4x32-10 in the kernels (keyed by seed, GLOBAL particle index, step, iteration),
+                nothing but a few scalars crosses PCIe; results are independent of the number of GPUs.
+
+Particles are sharded by rank in contiguous blocks (rank-major global order); `comm` supplies the four
+small collectives, the engine exchanges resampled particles itself.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .binding import SMC_MAX_ESS_CAND, SMC_SET_FILT, SMC_SET_PRED
+from .comm import SingleComm
+
+
+@dataclass
+class SMCSettings:
+    """Hyper-parameters, names and defaults of Micmem_settings.py:15-31,47,53,63-67,90."""
+    n_particle: int = 1000
+    ess_limit: float = 0.5
+    mhstep_factor: float = 0.5
+    mhstep_factor_cov: float = 0.5
+    ad_mhstep_num: int = 20
+    mhstep_num: int = 5
+    r_threshold: float = 0.5
+    r_threshold_f: float = 0.7
+    r_threshold_min: float = 0.1
+    d_gamma_max: float = 1
+    gm_reduction_itr: int = 80
+    gm_reduction_rate: float = 0.7
+    itr_max: int = 50
+    est_sigma: bool = True
+    sigma_true: float = 5
+    seed: int = 20250205
+    rtol: float = 1e-3
+    atol: float = 1e-6
+    priors: dict = field(default_factory=lambda: {
+        "Vmax": {"dist": "uniform", "low": 0, "high": 10},
+        "Km": {"dist": "uniform", "low": 0, "high": 10},
+        "sigma": {"dist": "uniform", "low": 0, "high": 10},
+    })
+
+    @property
+    def num_est_params(self):
+        return len(self.priors)
+
+    def w_cov(self):
+        d = self.num_est_params            # Micmem_settings.py:94-97
+        w = np.ones((d, d))
+        for i in range(d):
+            w[i, :] = self.mhstep_factor_cov
+            w[i, i] = self.mhstep_factor
+        return w
+
+
+def sample_prior(priors: dict, n_particle: int) -> np.ndarray:
+    """Micmem_settings.py:69-87 - global NumPy RNG, one draw of size N per parameter, parameter-major."""
+    p_pred = np.zeros((n_particle, len(priors)))
+    for j, (name, p) in enumerate(priors.items()):
+        if p["dist"] == "normal":
+            p_pred[:, j] = np.random.normal(loc=p["mu"], scale=p["sigma"], size=n_particle)
+        elif p["dist"] == "uniform":
+            p_pred[:, j] = np.random.uniform(low=p["low"], high=p["high"], size=n_particle)
+        else:
+            raise ValueError(f"Unknown distribution: {p['dist']}")
+    return p_pred
+
+
+def ess_candidates(gamma_old: float, s: SMCSettings):
+    """The grid of tempering increments the reference's back-off visits, produced by its own recurrence
+    (main:111-113,121,141) in Python floats so the values are bit-identical to the reference's."""
+    gamma_new = gamma_old + s.d_gamma_max
+    if gamma_new > 1.0:
+        gamma_new = 1.0
+    gms, gammas = [], []
+    for _ in range(s.gm_reduction_itr):
+        gms.append(gamma_new - gamma_old)
+        gammas.append(gamma_new)
+        gamma_new = (gamma_new - gamma_old) * s.gm_reduction_rate + gamma_old
+    return gms, gammas, gamma_new
+
+
+def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_MAX_ESS_CAND):
+    """main:111-144.  Candidates are evaluated `chunk` at a time by one fused pass over lk each."""
+    n = s.n_particle
+    max_lk = float(comm.allreduce_max([engine.max_lk_local()])[0])            # :116
+    gms, gammas, gamma_after_all = ess_candidates(gamma_old, s)
+    iters = 0
+    launches = 0
+    ess = sum_w = None
+    k0 = 0
+    while k0 < len(gms):
+        part = gms[k0:k0 + chunk]
+        sw, sw2 = engine.ess_partials(max_lk, part)
+        launches += 1
+        tot = comm.allreduce_sum(np.concatenate([sw, sw2]))
+        sw, sw2 = tot[:len(part)], tot[len(part):]
+        for i in range(len(part)):
+            sum_w = float(sw[i])
+            ess = 1.0 / (float(sw2[i]) / (sum_w * sum_w)) / n                 # :130-134
+            iters += 1
+            if ess > s.ess_limit:                                             # :136
+                return {"gamma_new": gammas[k0 + i], "gm": part[i], "ess": ess, "sum_weight": sum_w, "max_lk": max_lk,
+                        "iters": iters, "launches": launches, "warning": False}
+        k0 += chunk
+    # no candidate passed: the weights of the last trial are kept, gamma has been shrunk once more (:141-144)
+    return {"gamma_new": gamma_after_all, "gm": gms[-1], "ess": ess, "sum_weight": sum_w, "max_lk": max_lk,
+            "iters": iters, "launches": launches, "warning": True}
+
+
+def resample(engine, comm, es: dict, wrand_u: float, s: SMCSettings, first_step: bool):
+    """main:147-184 across ranks: residual sums -> prefix; offspring -> output slot bases; gather/exchange."""
+    inv_Np = 1 / s.n_particle                                                 # Micmem_settings.py:17
+    wrand = wrand_u * inv_Np                                                  # :156
+    r_loc, c_loc = engine.resample_phase1(es["max_lk"], es["gm"], es["sum_weight"])
+    r_all = comm.allgather([r_loc])[:, 0]
+    prefix = 0.0
+    for q in range(comm.rank):                                               # running sum in rank order
+        prefix = prefix + float(r_all[q])
+    o_loc = engine.resample_phase2(es["max_lk"], es["gm"], es["sum_weight"], prefix, wrand)
+    o_all = comm.allgather_i64([o_loc])[:, 0]
+    bases = np.concatenate([[0], np.cumsum(o_all)[:-1]]).astype(np.int64)
+    engine.resample_phase3(bases, o_all, first_step)
+    c_all = int(comm.allreduce_sum_i64([c_loc])[0])
+    return {"n_offspring": int(o_all.sum()), "n_tmp_before": s.n_particle - c_all}
+
+
+def proposal_cov(engine, comm, s: SMCSettings, w_cov):
+    """np.cov(p_filt.T, bias=True) * w_cov  (main:212-215) from device partial sums."""
+    n = s.n_particle
+    mean = comm.allreduce_sum(engine.moment_sums_local()) / n                 # X.mean(axis=1)
+    cent = comm.allreduce_sum(engine.moment_centered_local(mean).ravel()).reshape(len(mean), len(mean))
+    cov = cent * np.true_divide(1, n)                                         # c *= 1/fact, fact = N (bias)
+    return cov * w_cov
+
+
+def mvn_transform(cov_m):
+    """The factor NumPy's legacy multivariate_normal multiplies standard normals with:
+    x = z @ (sqrt(s)[:,None] * v), (u,s,v) = svd(cov)."""
+    (u, sv, v) = np.linalg.svd(cov_m)
+    return np.sqrt(sv)[:, None] * v
+
+
+def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy", verbose: bool = True,
+            p_pred0=None, seed_device: int | None = None, log=print):
+    """Run the tempering loop (main:95-262).  The engine must already hold the model and the prior.
+
+    Returns a dict: final particles (this rank's block), lk, schedule records, logZ, counters.
+    """
+    s = s or SMCSettings()
+    comm = comm or SingleComm()
+    n = s.n_particle
+    d = s.num_est_params
+    world, rank = comm.size, comm.rank
+    n_local = engine.n_local
+    assert n_local * world == n, "n_particle must equal world * n_local"
+    lo = rank * n_local
+    w_cov = s.w_cov()
+    start_time = time.perf_counter()
+    stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
+             "ess_launches": 0, "particle_mutation_steps": 0}
+
+    # ---- prior draw (Micmem_settings.py:47,84-87) ----
+    if rng == "numpy":
+        if p_pred0 is None:
+            np.random.seed(s.seed)
+            p_pred0 = sample_prior(s.priors, n)
+        engine.upload_particles(SMC_SET_PRED, np.ascontiguousarray(p_pred0[lo:lo + n_local]))
+        host_rng = None
+    elif rng == "device":
+        seed_device = s.seed if seed_device is None else seed_device
+        if p_pred0 is None:
+            engine.sample_prior_device(seed_device, lo)
+        else:
+            engine.upload_particles(SMC_SET_PRED, np.ascontiguousarray(p_pred0[lo:lo + n_local]))
+        host_rng = np.random.RandomState(seed_device & 0xFFFFFFFF)           # the one scalar draw per step (:156)
+    else:
+        raise ValueError("rng must be 'numpy' or 'device'")
+
+    def account(info):
+        stats["rk_attempts"] += info["rk_attempts"]
+        stats["n_failed"] += info["n_failed"]
+
+    info = engine.loglik(SMC_SET_PRED)                                        # main:98
+    account(info)
+    if int(comm.allreduce_sum_i64([info["n_failed"]])[0]):
+        raise RuntimeError("an RK45 solve failed in the initial sweep (the reference raises here)")
+
+    gamma_old, gamma_new = 0.0, 1.0
+    records = []
+    logZ = 0.0
+    step = 0
+    for step in range(1, s.itr_max):                                          # :109
+        es = ess_search(engine, comm, gamma_old, s)                           # :111-144
+        gamma_new, ess, max_lk = es["gamma_new"], es["ess"], es["max_lk"]
+        stats["ess_iters"] += es["iters"]
+        stats["ess_launches"] += es["launches"]
+        if verbose and rank == 0:
+            if es["warning"]:
+                log("ess reduction warning: ess = ", ess)
+            else:
+                log(f"ess>ess_limit:{ess}")
+        dlogZ = es["gm"] * max_lk + math.log(es["sum_weight"] / n)
+        logZ += dlogZ
+        wrand_u = np.random.rand() if rng == "numpy" else host_rng.rand()     # :156
+        rs = resample(engine, comm, es, wrand_u, s, first_step=(step == 1))   # :147-184
+        if verbose and rank == 0:
+            log("n_tmp:", rs["n_tmp_before"])
+        engine.reset_accept_flags()                                           # :187
+        mhstep_ratio = 1.0                                                    # :190
+        if gamma_new >= 1.0:                                                  # :193-208
+            nMH, r_th = s.ad_mhstep_num, s.r_threshold_f
+        else:
+            nMH, r_th = s.mhstep_num, s.r_threshold
+        j = 0
+        acc_ever = 0
+        mh_log = []
+        for j in range(nMH):                                                  # :209
+            cov_m = proposal_cov(engine, comm, s, w_cov)                      # :212-215
+            if rng == "numpy":
+                noise = np.random.multivariate_normal(np.zeros(d), cov_m, n)  # :220
+                rr = np.random.uniform(0, 1, n)                               # :235
+                out = engine.mh_step_host_rng(gamma_new, mhstep_ratio, noise[lo:lo + n_local], rr[lo:lo + n_local])
+            else:
+                out = engine.mh_step_device_rng(gamma_new, mhstep_ratio, mvn_transform(cov_m), seed_device,
+                                                (step << 16) | j, lo)
+            account(out)
+            stats["rk_attempts_mh"] += out["rk_attempts"]
+            stats["mutation_sweeps"] += 1
+            stats["particle_mutation_steps"] += n
+            tot = comm.allreduce_sum_i64([out["accepted_ever"], out["accepted_now"], out["n_failed"]])
+            acc_ever = int(tot[0])
+            mh_log.append({"cov_m": cov_m, "mhstep_ratio": mhstep_ratio, "accepted_now": int(tot[1]),
+                           "accepted_ever": acc_ever})
+            if int(tot[2]):
+                raise RuntimeError("an RK45 solve failed during an MH sweep (the reference raises here)")
+            if acc_ever > r_th * n:                                           # :243
+                if verbose and rank == 0:
+                    log(f"r_ac.sum() > r_th * n_particle:{float(acc_ever)}")
+                break
+            if acc_ever < s.r_threshold_min * n:                              # :247
+                mhstep_ratio = mhstep_ratio * 0.5
+                if verbose and rank == 0:
+                    log(mhstep_ratio)
+        engine.commit_filt_to_pred()                                          # :251-252
+        if verbose and rank == 0:
+            log(f"iteration:{step}, nMH:{j}, Calculation time:{time.perf_counter() - start_time}, ESS:{ess}, "
+                f"Max Likelihood:{max_lk}, New Gamma:{gamma_new}, Number of Adoption:{float(acc_ever)}")
+        records.append({"step": step, "gamma_old": gamma_old, "gamma_new": gamma_new, "gm": es["gm"], "ess": ess,
+                        "ess_iters": es["iters"], "sum_weight": es["sum_weight"], "max_lk": max_lk, "dlogZ": dlogZ,
+                        "wrand_u": wrand_u, "last_j": j, "n_accept": float(acc_ever), "n_offspring": rs["n_offspring"],
+                        "n_tmp_before": rs["n_tmp_before"], "mh": mh_log})
+        if gamma_new == 1.0:                                                  # :259
+            break
+        gamma_old = gamma_new
+    if gamma_new < 1.0 and verbose and rank == 0:
+        log("tempering does't complete: last gamma =", gamma_new)             # :270-271
+    engine.synchronize()
+    return {"p_pred": engine.download_particles(SMC_SET_PRED), "lk": engine.download_lk(SMC_SET_PRED),
+            "records": records, "logZ": logZ, "gamma": gamma_new, "step": step, "stats": stats,
+            "wall_s": time.perf_counter() - start_time}

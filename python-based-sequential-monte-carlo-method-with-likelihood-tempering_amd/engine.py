@@ -1,0 +1,304 @@
+"""HipEngine - Python handle on one libsmc_hip.so context (one per process and GPU).
+
+Every method is a thin call through the C ABI (include/smc_hip.h); all arithmetic happens in the
+HIP kernels.  NumPy is used only to own the host buffers the reference would own
+("Ownership").
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import binding as B
+from .binding import SMC_SET_FILT, SMC_SET_PRED, SmcError, check, lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(B.c_dp)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class HipEngine:
+    """Device-resident particle sets p_pred/lk and p_filt/lk1 plus the stages that act on them."""
+
+    def __init__(self, n_local: int, dim: int = 3, device: int = 0, n_global: int | None = None):
+        self.L = lib()
+        self.n_local = int(n_local)
+        self.n_global = int(n_global if n_global is not None else n_local)
+        self.dim = int(dim)
+        self.device = int(device)
+        self.rank, self.world = 0, 1
+        ctx = B.c_ctx()
+        st = self.L.smc_create(ctypes.byref(ctx), self.device, self.n_local, self.n_global, self.dim)
+        if st != 0:
+            msg = self.L.smc_last_error(None)
+            raise SmcError(f"smc_create: {msg.decode() if msg else 'unknown error'}")
+        self.ctx = ctx
+        self.model = None
+
+    # ---- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.smc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, st, what):
+        check(self.ctx, st, what)
+
+    def synchronize(self):
+        self._ck(self.L.smc_synchronize(self.ctx), "smc_synchronize")
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        arch = ctypes.create_string_buffer(256)
+        cu = ctypes.c_int(0)
+        self._ck(self.L.smc_device_info(self.ctx, name, 256, arch, 256, ctypes.byref(cu)), "smc_device_info")
+        return {"name": name.value.decode(), "arch": arch.value.decode(), "cu_count": cu.value}
+
+    # ---- model / prior -------------------------------------------------------------------------
+    def set_model_mm(self, t, P_obs, S0, est_sigma=True, sigma_fixed=5.0, rtol=1e-3, atol=1e-6):
+        t = _f64(t)
+        P_obs = _f64(P_obs, t.shape)
+        S0 = _f64(S0, (t.shape[0],))
+        self._ck(self.L.smc_set_model_mm(self.ctx, _dp(t), _dp(P_obs), _dp(S0), t.shape[0], t.shape[1],
+                                         int(bool(est_sigma)), float(sigma_fixed), float(rtol), float(atol)),
+                 "smc_set_model_mm")
+        self.model = ("mm", t.shape[0], t.shape[1])
+
+    def set_prior(self, priors: dict):
+        """priors: the reference's dict (Micmem_settings.py:55-67), one entry per parameter, in order."""
+        kinds, a, b = [], [], []
+        for name, p in priors.items():
+            if p["dist"] == "uniform":
+                kinds.append(B.SMC_PRIOR_UNIFORM)
+                a.append(p["low"])
+                b.append(p["high"])
+            elif p["dist"] == "normal":
+                kinds.append(B.SMC_PRIOR_NORMAL)
+                a.append(p["mu"])
+                b.append(p["sigma"])
+            else:
+                raise ValueError(f"Unknown prior: {p['dist']}")
+        k = np.array(kinds, dtype=np.int32)
+        a = np.array(a, dtype=np.float64)
+        b = np.array(b, dtype=np.float64)
+        self._ck(self.L.smc_set_prior(self.ctx, k.ctypes.data_as(B.c_ip), _dp(a), _dp(b), len(kinds)), "smc_set_prior")
+
+    # ---- movement ------------------------------------------------------------------------------
+    def upload_particles(self, which, aos):
+        aos = _f64(aos)
+        assert aos.ndim == 2 and aos.shape[1] == self.dim
+        self._ck(self.L.smc_upload_particles(self.ctx, which, _dp(aos), aos.shape[0]), "smc_upload_particles")
+
+    def download_particles(self, which, n=None):
+        n = self.n_local if n is None else n
+        out = np.empty((n, self.dim))
+        self._ck(self.L.smc_download_particles(self.ctx, which, _dp(out), n), "smc_download_particles")
+        return out
+
+    def upload_lk(self, which, lk):
+        lk = _f64(lk)
+        self._ck(self.L.smc_upload_lk(self.ctx, which, _dp(lk), lk.shape[0]), "smc_upload_lk")
+
+    def download_lk(self, which, n=None):
+        n = self.n_local if n is None else n
+        out = np.empty(n)
+        self._ck(self.L.smc_download_lk(self.ctx, which, _dp(out), n), "smc_download_lk")
+        return out
+
+    def download_accept_flags(self):
+        out = np.empty(self.n_local, dtype=np.uint8)
+        self._ck(self.L.smc_download_accept_flags(self.ctx, out.ctypes.data_as(B.c_u8p), self.n_local),
+                 "smc_download_accept_flags")
+        return out
+
+    def commit_filt_to_pred(self):
+        self._ck(self.L.smc_commit_filt_to_pred(self.ctx), "smc_commit_filt_to_pred")
+
+    def sample_prior_device(self, seed, global_offset=0):
+        self._ck(self.L.smc_sample_prior_device(self.ctx, int(seed), int(global_offset)), "smc_sample_prior_device")
+
+    # ---- likelihood ----------------------------------------------------------------------------
+    def loglik(self, which=SMC_SET_PRED):
+        nf, att = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._ck(self.L.smc_loglik(self.ctx, which, ctypes.byref(nf), ctypes.byref(att)), "smc_loglik")
+        return {"n_failed": nf.value, "rk_attempts": att.value}
+
+    def loglik_host(self, particle, want_pred=False):
+        particle = _f64(particle)
+        assert particle.ndim == 2 and particle.shape[1] == 3
+        n = particle.shape[0]
+        lk = np.empty(n)
+        pred = np.empty((n, self.model[1], self.model[2])) if want_pred else None
+        nf, att = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._ck(self.L.smc_mm_loglik_host(self.ctx, _dp(particle), n, _dp(lk), _dp(pred) if want_pred else None,
+                                           ctypes.byref(nf), ctypes.byref(att)), "smc_mm_loglik_host")
+        return lk, pred, {"n_failed": nf.value, "rk_attempts": att.value}
+
+    # ---- weights / ESS -------------------------------------------------------------------------
+    def max_lk_local(self):
+        v = ctypes.c_double(0)
+        self._ck(self.L.smc_max_lk_local(self.ctx, ctypes.byref(v)), "smc_max_lk_local")
+        return v.value
+
+    def ess_partials(self, max_lk, gms):
+        gms = _f64(gms)
+        k = gms.shape[0]
+        sw, sw2 = np.empty(k), np.empty(k)
+        self._ck(self.L.smc_ess_partials(self.ctx, float(max_lk), _dp(gms), k, _dp(sw), _dp(sw2)), "smc_ess_partials")
+        return sw, sw2
+
+    # ---- resampling ----------------------------------------------------------------------------
+    def resample_phase1(self, max_lk, gm, sum_w):
+        r, c = ctypes.c_double(0), ctypes.c_int64(0)
+        self._ck(self.L.smc_resample_phase1(self.ctx, float(max_lk), float(gm), float(sum_w), ctypes.byref(r),
+                                            ctypes.byref(c)), "smc_resample_phase1")
+        return r.value, c.value
+
+    def resample_phase2(self, max_lk, gm, sum_w, residual_prefix, wrand):
+        o = ctypes.c_int64(0)
+        self._ck(self.L.smc_resample_phase2(self.ctx, float(max_lk), float(gm), float(sum_w), float(residual_prefix),
+                                            float(wrand), ctypes.byref(o)), "smc_resample_phase2")
+        return o.value
+
+    def download_offspring(self):
+        out = np.empty(self.n_local, dtype=np.int64)
+        self._ck(self.L.smc_download_offspring(self.ctx, out.ctypes.data_as(B.c_i64p), self.n_local),
+                 "smc_download_offspring")
+        return out
+
+    def resample_phase3(self, out_base_all, offspring_all, first_step):
+        b = np.ascontiguousarray(out_base_all, dtype=np.int64)
+        o = np.ascontiguousarray(offspring_all, dtype=np.int64)
+        assert b.shape == o.shape == (self.world,)
+        self._ck(self.L.smc_resample_phase3(self.ctx, b.ctypes.data_as(B.c_i64p), o.ctypes.data_as(B.c_i64p),
+                                            int(bool(first_step))), "smc_resample_phase3")
+
+    # ---- moments -------------------------------------------------------------------------------
+    def moment_sums_local(self):
+        out = np.empty(self.dim)
+        self._ck(self.L.smc_moment_sums_local(self.ctx, _dp(out)), "smc_moment_sums_local")
+        return out
+
+    def moment_centered_local(self, mean):
+        mean = _f64(mean, (self.dim,))
+        out = np.empty((self.dim, self.dim))
+        self._ck(self.L.smc_moment_centered_local(self.ctx, _dp(mean), _dp(out)), "smc_moment_centered_local")
+        return out
+
+    # ---- MH ------------------------------------------------------------------------------------
+    def reset_accept_flags(self):
+        self._ck(self.L.smc_reset_accept_flags(self.ctx), "smc_reset_accept_flags")
+
+    def _mh_out(self):
+        return [ctypes.c_int64(0) for _ in range(4)]
+
+    def mh_step_host_rng(self, gamma, mhstep_ratio, noise, rr):
+        noise = _f64(noise, (self.n_local, self.dim))
+        rr = _f64(rr, (self.n_local,))
+        o = self._mh_out()
+        self._ck(self.L.smc_mh_step_host_rng(self.ctx, float(gamma), float(mhstep_ratio), _dp(noise), _dp(rr),
+                                             self.n_local, *[ctypes.byref(x) for x in o]), "smc_mh_step_host_rng")
+        return {"accepted_now": o[0].value, "accepted_ever": o[1].value, "n_failed": o[2].value,
+                "rk_attempts": o[3].value}
+
+    def mh_step_device_rng(self, gamma, mhstep_ratio, transform, seed, stream, global_offset=0):
+        transform = _f64(transform, (self.dim, self.dim))
+        o = self._mh_out()
+        self._ck(self.L.smc_mh_step_device_rng(self.ctx, float(gamma), float(mhstep_ratio), _dp(transform), int(seed),
+                                               int(stream), int(global_offset), *[ctypes.byref(x) for x in o]),
+                 "smc_mh_step_device_rng")
+        return {"accepted_now": o[0].value, "accepted_ever": o[1].value, "n_failed": o[2].value,
+                "rk_attempts": o[3].value}
+
+    def set_debug_capture(self, enable=True):
+        self._ck(self.L.smc_set_debug_capture(self.ctx, int(enable)), "smc_set_debug_capture")
+
+    def download_debug_proposals(self):
+        n = self.n_local
+        aos, lk2 = np.empty((n, self.dim)), np.empty(n)
+        p0, r = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8)
+        self._ck(self.L.smc_download_debug_proposals(self.ctx, _dp(aos), _dp(lk2), p0.ctypes.data_as(B.c_u8p),
+                                                     r.ctypes.data_as(B.c_u8p), n), "smc_download_debug_proposals")
+        return aos, lk2, p0, r
+
+    # ---- collectives (RCCL) --------------------------------------------------------------------
+    @staticmethod
+    def comm_get_unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * 128)()
+        st = lib().smc_comm_get_unique_id(buf)
+        if st != 0:
+            msg = lib().smc_last_error(None)
+            raise SmcError(f"smc_comm_get_unique_id: {msg.decode() if msg else ''}")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self.L.smc_comm_init(self.ctx, buf, int(rank), int(world)), "smc_comm_init")
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_allreduce_sum_f64(self, x):
+        x = _f64(x).copy()
+        self._ck(self.L.smc_comm_allreduce_sum_f64(self.ctx, _dp(x), x.size), "smc_comm_allreduce_sum_f64")
+        return x
+
+    def comm_allreduce_max_f64(self, x):
+        x = _f64(x).copy()
+        self._ck(self.L.smc_comm_allreduce_max_f64(self.ctx, _dp(x), x.size), "smc_comm_allreduce_max_f64")
+        return x
+
+    def comm_allreduce_sum_i64(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int64).copy()
+        self._ck(self.L.smc_comm_allreduce_sum_i64(self.ctx, x.ctypes.data_as(B.c_i64p), x.size),
+                 "smc_comm_allreduce_sum_i64")
+        return x
+
+    def comm_allgather_f64(self, x):
+        x = _f64(x)
+        out = np.empty((self.world,) + x.shape)
+        self._ck(self.L.smc_comm_allgather_f64(self.ctx, _dp(x), x.size, _dp(out)), "smc_comm_allgather_f64")
+        return out
+
+    def comm_allgather_i64(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int64)
+        out = np.empty((self.world,) + x.shape, dtype=np.int64)
+        self._ck(self.L.smc_comm_allgather_i64(self.ctx, x.ctypes.data_as(B.c_i64p), x.size,
+                                               out.ctypes.data_as(B.c_i64p)), "smc_comm_allgather_i64")
+        return out
+
+    def comm_barrier(self):
+        self._ck(self.L.smc_comm_barrier(self.ctx), "smc_comm_barrier")
+
+    # ---- timing --------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._ck(self.L.smc_timing_enable(self.ctx, int(on)), "smc_timing_enable")
+
+    def timing_reset(self):
+        self._ck(self.L.smc_timing_reset(self.ctx), "smc_timing_reset")
+
+    def timing_get(self):
+        out = {}
+        for which, name in B.TIMING_NAMES.items():
+            n, ms = ctypes.c_int64(0), ctypes.c_double(0)
+            self._ck(self.L.smc_timing_get(self.ctx, which, ctypes.byref(n), ctypes.byref(ms)), "smc_timing_get")
+            out[name] = {"launches": n.value, "ms": ms.value}
+        return out

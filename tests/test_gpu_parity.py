@@ -1,0 +1,427 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the pinned CPU oracle
+on the same seeded inputs, against the golden fixtures, and - at BASELINE.json's full size (1e6
+particles) - through size-independent properties.
+
+Floating-point tolerances (all arithmetic is float64):
+  TOL_LOGL   1e-9  relative on a particle's log-likelihood.  Sources of difference vs the oracle:
+             FMA contraction inside the RK45 stage sums, device exp/pow/log (<= 1-2 ulp) vs glibc,
+             amplified by ~116 adaptive steps per solve.  Observed: ~1e-12.
+  TOL_SUM    1e-12 relative on reductions over N (different summation order).
+Integer / index work (offspring counts, ancestor indices, accept flags and counts) is compared
+exactly.
+"""
+import numpy as np
+import pytest
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL_LOGL = 1e-9
+TOL_SUM = 1e-12
+
+
+@pytest.fixture(scope="module")
+def settings(pkg):
+    return pkg.SMCSettings()
+
+
+def make_engine(pkg, data, n, priors=None, **kw):
+    eng = pkg.HipEngine(n, 3, device=0, **kw)
+    eng.set_model_mm(data.t, data.P_obs, data.S0)
+    eng.set_prior(priors or pkg.SMCSettings().priors)
+    return eng
+
+
+def mixed_particles(n, seed=0):
+    rs = np.random.RandomState(seed)
+    th = np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((n, 3)) * np.array([0.025, 0.0295, 0.00094])
+    k = n // 2
+    th[:k] = rs.uniform(0, 10, size=(k, 3))
+    return th
+
+
+# ---------------------------------------------------------------------------------------------------
+# A2: likelihood
+# ---------------------------------------------------------------------------------------------------
+def test_loglik_known_answers_from_reference(pkg, data, known_answers):
+    """Directly against values the reference's log_likelihood_mm_multi produced (golden fixture)."""
+    th = known_answers["theta"]
+    with make_engine(pkg, data, len(th)) as eng:
+        lk, pred, info = eng.loglik_host(th, want_pred=True)
+    assert info["n_failed"] == 0
+    assert relerr(lk, known_answers["logL"]).max() < TOL_LOGL
+    assert np.abs(pred - known_answers["pred"]).max() < 1e-9
+
+
+def test_loglik_first_sweep_of_reference_run(pkg, data, golden_run):
+    th, ref = golden_run["sweeps_theta"][0], golden_run["sweeps_llk"][0]
+    with make_engine(pkg, data, len(th)) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+    assert info["n_failed"] == 0
+    assert relerr(lk, ref).max() < TOL_LOGL
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 20000])
+def test_loglik_vs_oracle(pkg, O, data, n):
+    th = mixed_particles(n, seed=n)
+    ref, _, oinfo = O.mm_loglik_batch(th, data)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+    assert info["n_failed"] == 0 and oinfo["n_failed"] == 0
+    assert relerr(lk, ref).max() < TOL_LOGL
+    # same adaptive step sequence: the device-counted attempts equal the oracle's
+    assert info["rk_attempts"] == oinfo["n_attempts"]
+
+
+def test_loglik_corner_cases(pkg, O, data):
+    th = np.array([[1.0, 1.0, 0.0], [1.0, 1.0, -3.0], [0.0, 1.0, 1.0], [10.0, 10.0, 10.0], [1e-6, 1e-6, 1e-3],
+                   [5.0, 1e-8, 0.1], [9.99, 1e-3, 0.5], [1.2, 0.5, 1e-6], [1.0, 1.0, np.nan]])
+    ref, _, _ = O.mm_loglik_batch(th, data)
+    with make_engine(pkg, data, len(th)) as eng:
+        lk, _, info = eng.loglik_host(th)
+    assert np.isneginf(lk[0]) and np.isneginf(lk[1])          # sigma <= 0 -> -inf (Micmem_likelihood.py:53-54)
+    assert np.isnan(lk[-1]) and np.isnan(ref[-1])
+    assert relerr(lk[2:-1], ref[2:-1]).max() < TOL_LOGL
+
+
+def test_loglik_fixed_sigma(pkg, O, data):
+    th = mixed_particles(500, seed=9)
+    ref, _, _ = O.mm_loglik_batch(th, data, est_sigma=False, sigma_fixed=0.05)
+    with pkg.HipEngine(500, 3) as eng:
+        eng.set_model_mm(data.t, data.P_obs, data.S0, est_sigma=False, sigma_fixed=0.05)
+        lk, _, _ = eng.loglik_host(th)
+    assert relerr(lk, ref).max() < TOL_LOGL
+
+
+def test_loglik_ragged_data_shapes(pkg, O):
+    """Other data-set shapes than 6x40 (n_ex, n_t are run-time parameters of the kernel)."""
+    rs = np.random.RandomState(4)
+    for n_ex, n_t in [(1, 2), (3, 17), (16, 40), (2, 256)]:
+        t = np.sort(rs.uniform(0, 8, size=(n_ex, n_t)), axis=1)
+        t[:, 0] = 0.0
+        P = rs.uniform(0, 1, size=(n_ex, n_t))
+        S0 = rs.uniform(0.1, 3, size=n_ex)
+        d = O.MMData(t, P, S0)
+        th = rs.uniform(0.05, 5, size=(130, 3))
+        ref, _, _ = O.mm_loglik_batch(th, d)
+        with pkg.HipEngine(130, 3) as eng:
+            eng.set_model_mm(t, P, S0)
+            lk, _, info = eng.loglik_host(th)
+        assert info["n_failed"] == 0
+        assert relerr(lk, ref).max() < TOL_LOGL, (n_ex, n_t)
+
+
+# ---------------------------------------------------------------------------------------------------
+# A3/A4: weights, ESS, max
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 100, 1000, 100003])
+def test_max_and_ess_partials(pkg, O, data, n):
+    rs = np.random.RandomState(n)
+    lk = -np.abs(rs.standard_normal(n)) * 300 + 100
+    s = O.SMCSettings()
+    gms, gammas, _ = O.ess_candidates(0.1, s)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        mx = eng.max_lk_local()
+        assert mx == lk.max()
+        for k0, k1 in [(0, 16), (16, 21), (40, 41), (50, 58)]:
+            sw, sw2 = eng.ess_partials(mx, gms[k0:k1])
+            for i, gm in enumerate(gms[k0:k1]):
+                w = np.exp((lk - mx) * gm)
+                assert abs(sw[i] - w.sum()) <= TOL_SUM * w.sum()
+                assert abs(sw2[i] - (w * w).sum()) <= TOL_SUM * (w * w).sum()
+
+
+def test_ess_search_matches_oracle(pkg, O, data, golden_run):
+    lk = golden_run["sweeps_llk"][0]
+    s = O.SMCSettings()
+    ref = O.ess_search(lk, 0.0, s)
+    with make_engine(pkg, data, len(lk)) as eng:
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        es = pkg.ess_search(eng, pkg.SingleComm(), 0.0, pkg.SMCSettings())
+    assert es["gamma_new"] == ref["gamma_new"] == golden_run["sched_gamma"][0]
+    assert es["iters"] == ref["iters"] and es["gm"] == ref["gm"]
+    assert abs(es["ess"] - ref["ess"]) < 1e-12
+    assert abs(es["sum_weight"] - ref["sum_weight"]) <= TOL_SUM * ref["sum_weight"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# A5: resampling
+# ---------------------------------------------------------------------------------------------------
+def _resample_case(pkg, O, data, n, gm, seed, first_step=True, spread=30.0):
+    rs = np.random.RandomState(seed)
+    lk = rs.standard_normal(n) * spread
+    p_pred = rs.standard_normal((n, 3))
+    u = rs.rand()
+    mx = lk.max()
+    w = np.exp((lk - mx) * gm)
+    sum_w = np.sum(w)
+    w = w / sum_w
+    p_filt = np.zeros((n, 3))
+    lk1 = np.zeros(n)
+    p_is, n_written, n_tmp = O.resample(w, u, p_pred, lk, p_filt, lk1)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, p_pred)
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        s = pkg.SMCSettings(n_particle=n)
+        es = {"max_lk": mx, "gm": gm, "sum_weight": float(sum_w)}
+        out = pkg.resample(eng, pkg.SingleComm(), es, u, s, first_step=first_step)
+        got_is = eng.download_offspring()
+        got_f = eng.download_particles(pkg.SMC_SET_FILT)
+        got_l = eng.download_lk(pkg.SMC_SET_FILT)
+    return (p_is, n_written, p_filt, lk1), (got_is, out["n_offspring"], got_f, got_l)
+
+
+@pytest.mark.parametrize("n,gm", [(1, 1.0), (2, 0.3), (255, 0.05), (1000, 0.002), (1024, 0.05), (1025, 1.0),
+                                  (4097, 0.01), (50000, 0.004)])
+def test_resample_vs_oracle(pkg, O, data, n, gm):
+    ref, got = _resample_case(pkg, O, data, n, gm, seed=n)
+    assert np.array_equal(got[0], ref[0])          # offspring counts: exact
+    assert got[1] == ref[1] == n
+    assert np.array_equal(got[2], ref[2])          # gathered rows: exact copies in ancestor order
+    assert np.array_equal(got[3], ref[3])
+
+
+def test_resample_golden_first_step(pkg, O, data, golden_run):
+    """The reference run's first tempering step: weights from its first sweep, wrand from its seed."""
+    g = golden_run
+    s = O.SMCSettings()
+    np.random.seed(int(g["seed"]))
+    p_pred = O.sample_prior(s.priors, 1000)
+    assert np.array_equal(p_pred, g["sweeps_theta"][0])
+    lk = g["sweeps_llk"][0]
+    es = O.ess_search(lk, 0.0, s)
+    u = np.random.rand()
+    p_filt, lk1 = np.zeros((1000, 3)), np.zeros(1000)
+    p_is, _, _ = O.resample(es["p_weight"], u, p_pred, lk, p_filt, lk1)
+    with make_engine(pkg, data, 1000) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, p_pred)
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        des = pkg.ess_search(eng, pkg.SingleComm(), 0.0, pkg.SMCSettings())
+        pkg.resample(eng, pkg.SingleComm(), des, u, pkg.SMCSettings(), first_step=True)
+        assert np.array_equal(eng.download_offspring(), p_is)
+        assert np.array_equal(eng.download_particles(pkg.SMC_SET_FILT), p_filt)
+
+
+def test_resample_full_size_properties(pkg, data):
+    """N = 1e6 (BASELINE config 2): offspring sum to N, every count >= trunc(N w), and the output is
+    exactly np.repeat(ancestors, counts) - pure index work, compared bit for bit."""
+    n = 1_000_000
+    rs = np.random.RandomState(123)
+    lk = rs.standard_normal(n) * 5
+    p_pred = rs.standard_normal((n, 3))
+    mx, gm = lk.max(), 0.37
+    w = np.exp((lk - mx) * gm)
+    sum_w = float(np.sum(w))
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, p_pred)
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        s = pkg.SMCSettings(n_particle=n)
+        out = pkg.resample(eng, pkg.SingleComm(), {"max_lk": mx, "gm": gm, "sum_weight": sum_w}, 0.4321, s, True)
+        p_is = eng.download_offspring()
+        f = eng.download_particles(pkg.SMC_SET_FILT)
+        l = eng.download_lk(pkg.SMC_SET_FILT)
+    assert out["n_offspring"] == n == p_is.sum()
+    base = np.trunc(w / sum_w * n).astype(np.int64)
+    extra = p_is - base
+    assert extra.min() >= 0 and extra.max() <= 1
+    anc = np.repeat(np.arange(n), p_is)
+    assert np.array_equal(f, p_pred[anc]) and np.array_equal(l, lk[anc])
+
+
+# ---------------------------------------------------------------------------------------------------
+# A6: moments
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 1000, 65537])
+def test_proposal_cov_vs_numpy(pkg, data, n):
+    rs = np.random.RandomState(n)
+    x = np.array([1.2, 0.5, 0.02]) + rs.standard_normal((n, 3)) * np.array([0.03, 0.03, 0.001])
+    s = pkg.SMCSettings(n_particle=n)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_FILT, x)
+        cov = pkg.proposal_cov(eng, pkg.SingleComm(), s, s.w_cov())
+    ref = np.cov(x.T, bias=True) * s.w_cov()
+    assert np.abs(cov - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------------------------------------------
+# A7-A9: fused MH iteration
+# ---------------------------------------------------------------------------------------------------
+def _mh_reference(O, data, priors, p_filt, lk1, noise, rr, gamma, ratio):
+    p_pred = p_filt + noise * ratio
+    p0 = np.int32(O.cal_prior(p_pred, priors) > 0)
+    p_pred = p_pred * p0[:, None] + p_filt * (1.0 - p0[:, None])
+    lk2, _, _ = O.mm_loglik_batch(p_pred, data)
+    with np.errstate(over="ignore"):
+        pp = np.exp((lk2 - lk1) * gamma) * p0
+    r = np.int32(pp >= rr)
+    return p_pred, p0, lk2, r, p_pred * r[:, None] + p_filt * (1.0 - r[:, None]), lk2 * r + lk1 * (1.0 - r)
+
+
+@pytest.mark.parametrize("n,gamma,ratio", [(1000, 0.0023, 1.0), (1000, 1.0, 0.5), (4099, 0.2, 1.0)])
+def test_mh_step_host_rng_vs_oracle(pkg, O, data, n, gamma, ratio):
+    rs = np.random.RandomState(n + int(gamma * 1000))
+    p_filt = mixed_particles(n, seed=n + 1)
+    lk1, _, _ = O.mm_loglik_batch(p_filt, data)
+    cov = np.cov(p_filt.T, bias=True) * pkg.SMCSettings().w_cov()
+    noise = rs.multivariate_normal(np.zeros(3), cov, n)
+    rr = rs.uniform(0, 1, n)
+    priors = pkg.SMCSettings().priors
+    prop, p0, lk2, r, f_ref, l_ref = _mh_reference(O, data, priors, p_filt, lk1, noise, rr, gamma, ratio)
+    with make_engine(pkg, data, n) as eng:
+        eng.set_debug_capture(True)
+        eng.upload_particles(pkg.SMC_SET_FILT, p_filt)
+        eng.upload_lk(pkg.SMC_SET_FILT, lk1)
+        out = eng.mh_step_host_rng(gamma, ratio, noise, rr)
+        d_prop, d_lk2, d_p0, d_r = eng.download_debug_proposals()
+        f = eng.download_particles(pkg.SMC_SET_FILT)
+        l = eng.download_lk(pkg.SMC_SET_FILT)
+        flags = eng.download_accept_flags()
+    assert np.array_equal(d_prop, prop)                 # proposals: same separately rounded mul/add as NumPy
+    assert np.array_equal(d_p0, p0)
+    assert relerr(d_lk2, lk2).max() < TOL_LOGL
+    assert np.array_equal(d_r, r), "accept decisions differ"
+    assert np.array_equal(f, f_ref)
+    assert relerr(l, l_ref).max() < TOL_LOGL
+    assert out["accepted_now"] == int(r.sum()) == out["accepted_ever"] == int(flags.sum())
+    assert out["n_failed"] == 0
+
+
+def test_mh_prior_mask_mixed_priors(pkg, O, data):
+    """normal + uniform priors: the support mask is cal_prior(...) > 0 (Micmem_SMC_main.py:225-226)."""
+    n = 777
+    priors = {"Vmax": {"dist": "normal", "mu": 1.0, "sigma": 0.1}, "Km": {"dist": "normal", "mu": 0.0, "sigma": 5.0},
+              "sigma": {"dist": "uniform", "low": 0.01, "high": 0.03}}
+    rs = np.random.RandomState(8)
+    p_filt = np.array([1.2, 0.5, 0.02]) + rs.standard_normal((n, 3)) * np.array([0.02, 0.02, 0.0005])
+    p_filt[:, 2] = np.clip(p_filt[:, 2], 0.0101, 0.0299)
+    lk1, _, _ = O.mm_loglik_batch(p_filt, data)
+    noise = rs.standard_normal((n, 3)) * np.array([0.05, 0.05, 0.01])
+    noise[::50, 0] = 5.0   # |z| = 42 sigma: norm.pdf underflows to 0 -> out of support
+    rr = rs.uniform(0, 1, n)
+    prop, p0, lk2, r, f_ref, l_ref = _mh_reference(O, data, priors, p_filt, lk1, noise, rr, 1.0, 1.0)
+    assert 0 < p0.sum() < n
+    with make_engine(pkg, data, n, priors=priors) as eng:
+        eng.set_debug_capture(True)
+        eng.upload_particles(pkg.SMC_SET_FILT, p_filt)
+        eng.upload_lk(pkg.SMC_SET_FILT, lk1)
+        eng.mh_step_host_rng(1.0, 1.0, noise, rr)
+        d_prop, d_lk2, d_p0, d_r = eng.download_debug_proposals()
+        f = eng.download_particles(pkg.SMC_SET_FILT)
+    assert np.array_equal(d_p0, p0) and np.array_equal(d_r, r) and np.array_equal(f, f_ref)
+
+
+def test_accept_flags_accumulate(pkg, O, data):
+    n = 512
+    rs = np.random.RandomState(1)
+    p_filt = mixed_particles(n, seed=5)
+    lk1, _, _ = O.mm_loglik_batch(p_filt, data)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_FILT, p_filt)
+        eng.upload_lk(pkg.SMC_SET_FILT, lk1)
+        ever = np.zeros(n, dtype=np.uint8)
+        for it in range(3):
+            noise = rs.standard_normal((n, 3)) * 0.01
+            rr = rs.uniform(0, 1, n)
+            before = eng.download_particles(pkg.SMC_SET_FILT)
+            out = eng.mh_step_host_rng(0.5, 1.0, noise, rr)
+            after = eng.download_particles(pkg.SMC_SET_FILT)
+            ever |= np.any(before != after, axis=1).astype(np.uint8)
+            assert out["accepted_ever"] >= int(ever.sum())
+            assert out["accepted_ever"] == int(eng.download_accept_flags().sum())
+        eng.reset_accept_flags()
+        assert eng.download_accept_flags().sum() == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole loop
+# ---------------------------------------------------------------------------------------------------
+def test_full_run_numpy_rng_matches_reference(pkg, data, golden_run):
+    """Config 1 (N=1000, seed 20250205) end to end on the GPU in host-RNG parity mode against the
+    reference run itself: gamma schedule bit-exact, ESS, accept counts and MH lengths exact,
+    posterior particles within 1e-9."""
+    g = golden_run
+    s = pkg.SMCSettings()
+    with make_engine(pkg, data, 1000) as eng:
+        out = pkg.run_smc(eng, s, rng="numpy", verbose=False)
+    rec = out["records"]
+    assert out["step"] == int(g["final_step"])
+    assert np.array_equal([r["gamma_new"] for r in rec], g["sched_gamma"])
+    assert np.allclose([r["ess"] for r in rec], g["sched_ess"], rtol=1e-10, atol=0)
+    assert np.array_equal([r["n_accept"] for r in rec], g["sched_accept"])
+    assert np.array_equal([r["last_j"] for r in rec], g["sched_last_j"])
+    assert np.allclose([r["max_lk"] for r in rec], g["sched_maxlk"], rtol=TOL_LOGL, atol=0)
+    assert np.abs(out["p_pred"] - g["final_p_pred"]).max() < 1e-9
+    assert relerr(out["lk"], g["final_lk"]).max() < TOL_LOGL
+    assert np.random.rand() == float(g["next_rand_after_run"])
+    assert abs(out["p_pred"].mean(axis=0) - g["final_p_pred"].mean(axis=0)).max() < 1e-12
+    assert out["stats"]["mutation_sweeps"] == g["sweeps_theta"].shape[0] - 1
+
+
+def test_full_run_logz_matches_oracle(pkg, O, data):
+    o = O.run_smc(data, O.SMCSettings(), seed=7, n_threads=0, record_mh=False)
+    s = pkg.SMCSettings(seed=7)
+    with make_engine(pkg, data, 1000) as eng:
+        out = pkg.run_smc(eng, s, rng="numpy", verbose=False)
+    assert abs(out["logZ"] - o["logZ"]) < 1e-9 * abs(o["logZ"])
+    assert np.abs(out["p_pred"] - o["p_pred"]).max() < 1e-9
+
+
+def test_full_run_device_rng_statistics(pkg, data, golden_run):
+    """Device-RNG mode cannot share NumPy's stream; posterior moments must agree statistically with the
+    reference posterior (N=1000): |mean_gpu - mean_ref| <= 5 * std / sqrt(1000) per parameter."""
+    g = golden_run["final_p_pred"]
+    n = 65536
+    s = pkg.SMCSettings(n_particle=n)
+    with make_engine(pkg, data, n) as eng:
+        out = pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=99)
+    assert out["gamma"] == 1.0
+    m, sd = out["p_pred"].mean(axis=0), out["p_pred"].std(axis=0)
+    assert np.all(np.abs(m - g.mean(axis=0)) <= 5 * g.std(axis=0) / np.sqrt(1000))
+    assert np.all(np.abs(sd / g.std(axis=0) - 1) < 0.2)
+    assert 560 < out["logZ"] < 575
+
+
+def test_philox_known_answer_and_prior_draw(pkg, data):
+    """Philox4x32-10 known-answer vector (Random123) through a pure-Python restatement, and the device
+    prior draw against it."""
+    def philox(c, k):
+        M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+        c = list(c)
+        k = list(k)
+        for _ in range(10):
+            p0, p1 = M0 * c[0], M1 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+            k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+        return c
+    assert philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    n, seed, goff = 300, 0x1234567890ABCDEF, 5_000_000_000
+    pri = {"a": {"dist": "uniform", "low": 0, "high": 1}, "b": {"dist": "uniform", "low": 2, "high": 6},
+           "c": {"dist": "uniform", "low": -1, "high": 1}}
+    with make_engine(pkg, data, n, priors=pri) as eng:
+        eng.sample_prior_device(seed, goff)
+        x = eng.download_particles(pkg.SMC_SET_PRED)
+    for p in [0, 1, 77, 299]:
+        g = goff + p
+        for c, (lo, hi) in enumerate([(0, 1), (2, 6), (-1, 1)]):
+            stream = 0xFFFFFFFF00000000 | c
+            r = philox([g & 0xFFFFFFFF, g >> 32, stream & 0xFFFFFFFF, ((stream >> 32) << 8) & 0xFFFFFFFF],
+                       [seed & 0xFFFFFFFF, seed >> 32])
+            u = float(((r[0] >> 5) << 26) | (r[1] >> 6)) / 9007199254740992.0
+            assert x[p, c] == lo + (hi - lo) * u
+
+
+def test_errors_are_reported(pkg, data):
+    with pkg.HipEngine(10, 3) as eng:
+        with pytest.raises(pkg.SmcError):
+            eng.loglik(pkg.SMC_SET_PRED)              # model not set
+        with pytest.raises(pkg.SmcError):
+            eng.upload_particles(pkg.SMC_SET_PRED, np.zeros((11, 3)))   # exceeds capacity
+    with pytest.raises(pkg.SmcError):
+        pkg.HipEngine(10, 3, device=99)
