@@ -171,7 +171,8 @@ int smc_comm_barrier(smc_ctx *ctx);
 #define SMC_T_RESAMPLE 3
 #define SMC_T_MOMENTS 4
 #define SMC_T_MAX 5
-#define SMC_T_COUNT 6
+#define SMC_T_SOLVE 6 /* the persistent RK45 solve kernel alone (inside LOGLIK / MH sweeps) */
+#define SMC_T_COUNT 7
 int smc_timing_enable(smc_ctx *ctx, int enable);
 int smc_timing_reset(smc_ctx *ctx);
 int smc_timing_get(smc_ctx *ctx, int which, int64_t *launches, double *total_ms);

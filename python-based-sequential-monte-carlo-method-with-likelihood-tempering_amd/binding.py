@@ -16,9 +16,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "smc_hip.h")
 SMC_SET_PRED, SMC_SET_FILT = 0, 1
 SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL = 0, 1
 SMC_MAX_ESS_CAND = 16
-SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX = range(6)
+SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX, SMC_T_SOLVE = range(7)
 TIMING_NAMES = {SMC_T_LOGLIK: "loglik", SMC_T_MH: "mh", SMC_T_ESS: "ess", SMC_T_RESAMPLE: "resample",
-                SMC_T_MOMENTS: "moments", SMC_T_MAX: "max"}
+                SMC_T_MOMENTS: "moments", SMC_T_MAX: "max", SMC_T_SOLVE: "solve"}
 
 
 class SmcError(RuntimeError):

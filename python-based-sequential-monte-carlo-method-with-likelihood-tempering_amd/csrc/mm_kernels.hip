@@ -1,19 +1,27 @@
-// mm_kernels.hip -- the dominant kernels of the path: the Michaelis-Menten likelihood sweep (K1) and
-// the random-walk Metropolis iteration fused with it (K5).  gfx950 (MI355X) only.
+// mm_kernels.hip -- the dominant stage of the path: the Michaelis-Menten likelihood sweep
+// (sim_particle, Micmem_likelihood.py:79-92) and the random-walk Metropolis iteration built around
+// it (Micmem_SMC_main.py:220-241).  gfx950 (MI355X) only.
 //
-// Mapping (wave64): one workgroup = 64 particles x n_ex experiments = n_ex waves; wave e solves
-// experiment e for 64 CONSECUTIVE particles, so that
-//   - the particle parameters are read as three coalesced 512-byte rows (SoA, d x N in HBM),
-//   - the experiment's data (t, P_obs: 2 x n_t doubles) are wave-uniform LDS reads (broadcast when
-//     the lanes are at the same output index, which neighbouring particles mostly are),
-//   - lanes of a wave differ only in theta - after resampling neighbours are copies or close
-//     relatives (ancestor order), which keeps their adaptive step counts aligned.
-// The n_ex per-experiment sums meet in LDS; wave 0 adds them in experiment order (the order of the
-// reference's `logL_total += logL_i`, Micmem_likelihood.py:73) and finishes the particle: plain
-// likelihood (K1) or the Metropolis accept/select (K5, Micmem_SMC_main.py:220-241).
+// A sweep is three launches on the context's stream:
 //
-// Roofline: FP64 vector ALU (no contraction over a dimension > 7, hence no MFMA); HBM traffic is
-// ~100 B per particle against ~2e4 flop (DESIGN.md "Kernels").
+//   mm_propose_kernel   (MH only)  proposal = p_filt + noise*ratio, prior support mask, reset of
+//                       out-of-support proposals (:220-228).  HBM-bound, ~60 B/particle.
+//   mm_solve_kernel     one work item = one (particle, experiment) RK45 solve -> sum of squared
+//                       residuals.  FP64-VALU-bound: >99 % of the sweep.  PERSISTENT waves with
+//                       LANE-LEVEL dynamic scheduling: whenever enough lanes of a wave have finished
+//                       their item they are handed the next items of the wave's chunk; chunks come
+//                       from one global atomic counter (one atomic per 128 items).  Adaptive step
+//                       counts differ by 100x between particles over the prior; static mapping made
+//                       the early tempering steps 20-40x slower than the late ones (profiles/r01_a).
+//   mm_finish_kernel    per particle: the n_ex sums -> logL in experiment order (:70-73), then
+//                       either store it (likelihood sweep) or accept/select (:231-241).
+//
+// Item order: item = (block64 * n_ex + e) * 64 + l  <->  particle block64*64 + l, experiment e, so
+// consecutive items share the experiment (same LDS rows, broadcast reads) and read consecutive
+// particles (coalesced SoA rows).
+//
+// Roofline: FP64 vector ALU (no contraction over a dimension > 7, hence no MFMA); HBM traffic of a
+// whole sweep is ~200 B per particle against ~2e4 flop (DESIGN.md "Kernels").
 #include <hip/hip_runtime.h>
 
 #include "mm_rk45.h"
@@ -33,118 +41,200 @@ __device__ __forceinline__ double prior_pdf(int kind, double a, double b, double
         return (y >= 0.0 && y <= 1.0 && scale > 0.0) ? 1.0 / scale : 0.0;
     } else {
         const double y = (x - a) / b;
-        if (!(b > 0.0)) return __longlong_as_double(0x7ff8000000000000LL);
+        if (!(b > 0.0)) return quiet_nan();
         return exp(-(y * y) / 2.0) / 2.5066282746310002 / b;
     }
 }
 
-template <int MODE /*0 = likelihood only, 1 = fused MH*/, bool WRITE_PRED>
-__global__ void __launch_bounds__(1024)
-mm_sweep_kernel(MMModel mm, Prior prior, const double *theta_in /* may alias theta_filt */, int64_t stride, int64_t n,
-                double *lk_io, double *__restrict__ pred, MHParams mh, double *theta_filt,
-                uint8_t *__restrict__ r_ac, SweepCounters *__restrict__ counters, double *__restrict__ dbg_prop,
-                double *__restrict__ dbg_lk2, uint8_t *__restrict__ dbg_p0, uint8_t *__restrict__ dbg_r) {
+// ---------------------------------------------------------------------------------------------
+// proposal (Micmem_SMC_main.py:220-228)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int64_t stride, int64_t n,
+                  double *__restrict__ prop, int64_t pstride, uint8_t *__restrict__ p0_out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const double f0 = filt[p], f1 = filt[stride + p], f2 = filt[2 * stride + p];
+    double z0, z1, z2;
+    if (mh.device_rng) {
+        const uint64_t g = (uint64_t)(mh.global_offset + p);
+        const u32x4 ra = philox_block(mh.seed, g, mh.stream, 0);
+        const u32x4 rb = philox_block(mh.seed, g, mh.stream, 1);
+        // Box-Muller on (0,1] x [0,1)
+        const double ua = 1.0 - u01_from(ra.x, ra.y), ub = u01_from(ra.z, ra.w);
+        const double uc = 1.0 - u01_from(rb.x, rb.y), ud = u01_from(rb.z, rb.w);
+        const double ra_ = sqrt(-2.0 * log(ua)), rc_ = sqrt(-2.0 * log(uc));
+        double sa, ca;
+        sincos(6.283185307179586 * ub, &sa, &ca);
+        const double g0 = ra_ * ca, g1 = ra_ * sa, g2 = rc_ * cos(6.283185307179586 * ud);
+        // x = z @ transform  (NumPy multivariate_normal: z @ (sqrt(s)[:,None]*v))
+        const double *T = mh.transform;
+        z0 = g0 * T[0] + g1 * T[3] + g2 * T[6];
+        z1 = g0 * T[1] + g1 * T[4] + g2 * T[7];
+        z2 = g0 * T[2] + g1 * T[5] + g2 * T[8];
+    } else {
+        z0 = mh.noise[p];
+        z1 = mh.noise[n + p];
+        z2 = mh.noise[2 * n + p];
+    }
+    // separately rounded multiply and add, as NumPy evaluates `p_filt + noise * mhstep_ratio`
+    const double c0 = __dadd_rn(f0, __dmul_rn(z0, mh.ratio)), c1 = __dadd_rn(f1, __dmul_rn(z1, mh.ratio)),
+                 c2 = __dadd_rn(f2, __dmul_rn(z2, mh.ratio));
+    // support mask (cal_prior > 0, :225-226) and reset of out-of-support proposals (:228)
+    double pdf = prior_pdf(prior.kind[0], prior.a[0], prior.b[0], c0);
+    pdf = pdf * prior_pdf(prior.kind[1], prior.a[1], prior.b[1], c1);
+    pdf = pdf * prior_pdf(prior.kind[2], prior.a[2], prior.b[2], c2);
+    const double p0 = (pdf > 0.0) ? 1.0 : 0.0, q0 = 1.0 - p0;
+    prop[p] = __dadd_rn(__dmul_rn(c0, p0), __dmul_rn(f0, q0));
+    prop[pstride + p] = __dadd_rn(__dmul_rn(c1, p0), __dmul_rn(f1, q0));
+    prop[2 * pstride + p] = __dadd_rn(__dmul_rn(c2, p0), __dmul_rn(f2, q0));
+    p0_out[p] = (uint8_t)(p0 != 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// solve: persistent waves, lane-level dynamic scheduling
+// ---------------------------------------------------------------------------------------------
+constexpr int kSolveBlock = 256;   // 4 waves
+constexpr int kChunk = 128;        // items per global dequeue (2 per lane)
+constexpr int kRefillAt = 16;      // refill a wave once this many lanes are idle (or none is live)
+
+struct SolveArgs {
+    const double *theta;        // SoA rows: Vmax at [p], Km at [stride + p], sigma at [2*stride + p]
+    int64_t stride, n;
+    const uint8_t *p0;          // MH: support flags; items of particles with p0 == 0 are not solved
+    double *sum_r2;             // [e*n + p]
+    int *info;                  // [e*n + p]: attempts | failed << 30
+    double *pred;               // optional: P_model, [(p*n_ex + e)*n_t + i]
+    unsigned long long *queue;  // global item counter (zeroed before the launch)
+};
+
+template <bool WRITE_PRED>
+__global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, SolveArgs a) {
     extern __shared__ double smem[];
     const int n_ex = mm.n_ex, n_t = mm.n_t;
-    double *s_t = smem;                      // n_ex*n_t
-    double *s_P = s_t + n_ex * n_t;          // n_ex*n_t
-    double *s_part = s_P + n_ex * n_t;       // n_ex*64 partial sums of squares
-    int *s_flag = (int *)(s_part + n_ex * kWave);  // n_ex*64: attempts | failed<<30
-
+    double *s_t = smem;              // n_ex*n_t
+    double *s_P = s_t + n_ex * n_t;  // n_ex*n_t
+    double *s_S0 = s_P + n_ex * n_t; // n_ex
     for (int i = threadIdx.x; i < n_ex * n_t; i += blockDim.x) {
         s_t[i] = mm.t[i];
         s_P[i] = mm.P_obs[i];
     }
+    if (threadIdx.x < n_ex) s_S0[threadIdx.x] = mm.S0[threadIdx.x];
     __syncthreads();
 
+    // items are laid out in groups of 64 particles x n_ex experiments; the last group may be partial
+    const unsigned long long n_items = (unsigned long long)((a.n + kWave - 1) / kWave) * kWave * n_ex;
     const int lane = threadIdx.x & (kWave - 1);
-    const int e = threadIdx.x >> 6;  // wave index = experiment
-    const int64_t p = (int64_t)blockIdx.x * kWave + lane;
-    const bool valid = p < n;
+    const double rtol = mm.rtol, atol = mm.atol;
 
-    double th0 = 1.0, th1 = 1.0, th2 = 1.0;   // Vmax, Km, sigma of the point the likelihood is evaluated at
-    double f0 = 0, f1 = 0, f2 = 0;            // current p_filt row (MODE 1)
-    double p0 = 1.0;
-    if (valid) {
-        th0 = theta_in[p];
-        th1 = theta_in[stride + p];
-        th2 = theta_in[2 * stride + p];
-        if (MODE == 1) {
-            f0 = th0;
-            f1 = th1;
-            f2 = th2;
-            // ---- proposal (Micmem_SMC_main.py:220): p_filt + noise * mhstep_ratio ----
-            double z0, z1, z2;
-            if (mh.device_rng) {
-                const uint64_t g = (uint64_t)(mh.global_offset + p);
-                const u32x4 ra = philox_block(mh.seed, g, mh.stream, 0);
-                const u32x4 rb = philox_block(mh.seed, g, mh.stream, 1);
-                // Box-Muller on (0,1] x [0,1)
-                const double ua = 1.0 - u01_from(ra.x, ra.y), ub = u01_from(ra.z, ra.w);
-                const double uc = 1.0 - u01_from(rb.x, rb.y), ud = u01_from(rb.z, rb.w);
-                const double ra_ = sqrt(-2.0 * log(ua)), rc_ = sqrt(-2.0 * log(uc));
-                double sa, ca, sc, cc;
-                sincos(6.283185307179586 * ub, &sa, &ca);
-                sincos(6.283185307179586 * ud, &sc, &cc);
-                const double g0 = ra_ * ca, g1 = ra_ * sa, g2 = rc_ * cc;
-                (void)sc;
-                // x = z @ transform  (NumPy multivariate_normal: z @ (sqrt(s)[:,None]*v))
-                const double *T = mh.transform;
-                z0 = g0 * T[0] + g1 * T[3] + g2 * T[6];
-                z1 = g0 * T[1] + g1 * T[4] + g2 * T[7];
-                z2 = g0 * T[2] + g1 * T[5] + g2 * T[8];
-            } else {
-                z0 = mh.noise[p];
-                z1 = mh.noise[n + p];
-                z2 = mh.noise[2 * n + p];
+    MMItem it;
+    it.attempts = 0;
+    bool live = false;              // this lane holds a running item
+    int64_t out_idx = 0;            // e*n + p of the running item
+    double *pred_item = nullptr;
+    unsigned long long q_lo = 0, q_hi = 0;  // wave-uniform: the wave's current chunk
+    bool drained = false;           // wave-uniform: the global queue is empty
+
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(!live);
+        const int n_idle = __popcll(idle_mask);
+        if (!drained && (n_idle >= kRefillAt || n_idle == kWave)) {
+            if (q_lo == q_hi) {  // next chunk: one atomic per wave and kChunk items
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(a.queue, (unsigned long long)kChunk);
+                b = __shfl(b, 0);
+                q_lo = b;
+                q_hi = (b + kChunk < n_items) ? b + kChunk : n_items;
+                if (q_lo >= n_items) {
+                    drained = true;
+                    q_lo = q_hi = 0;
+                }
             }
-            // separately rounded multiply and add, as NumPy evaluates `p_filt + noise * mhstep_ratio`
-            double c0 = __dadd_rn(f0, __dmul_rn(z0, mh.ratio)), c1 = __dadd_rn(f1, __dmul_rn(z1, mh.ratio)),
-                   c2 = __dadd_rn(f2, __dmul_rn(z2, mh.ratio));
-            // ---- support mask (cal_prior > 0, :225-226) and reset of out-of-support proposals (:228) ----
-            double pdf = prior_pdf(prior.kind[0], prior.a[0], prior.b[0], c0);
-            pdf = pdf * prior_pdf(prior.kind[1], prior.a[1], prior.b[1], c1);
-            pdf = pdf * prior_pdf(prior.kind[2], prior.a[2], prior.b[2], c2);
-            p0 = (pdf > 0.0) ? 1.0 : 0.0;
-            const double q0 = 1.0 - p0;
-            th0 = __dadd_rn(__dmul_rn(c0, p0), __dmul_rn(f0, q0));
-            th1 = __dadd_rn(__dmul_rn(c1, p0), __dmul_rn(f1, q0));
-            th2 = __dadd_rn(__dmul_rn(c2, p0), __dmul_rn(f2, q0));
+            if (!drained) {
+                const unsigned long long avail = q_hi - q_lo;
+                const int my = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
+                const int take = (unsigned long long)n_idle < avail ? n_idle : (int)avail;
+                if (!live && my < take) {
+                    const unsigned long long item = q_lo + my;
+                    const unsigned long long grp = item >> 6;            // 64-item group
+                    const int e = (int)(grp % (unsigned)n_ex);
+                    const int64_t p = (int64_t)(grp / (unsigned)n_ex) * kWave + (int64_t)(item & 63);
+                    if (p < a.n) {
+                        out_idx = (int64_t)e * a.n + p;
+                        bool run = true;
+                        if (a.p0 && a.p0[p] == 0) run = false;          // masked proposal: lk2 == lk1, no solve
+                        const double Vmax = a.theta[p], Km = a.theta[a.stride + p];
+                        const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
+                        if (sigma <= 0.0) run = false;                   // -inf without solving (:53-54)
+                        if (run) {
+                            if (WRITE_PRED) pred_item = a.pred + ((size_t)p * n_ex + e) * n_t;
+                            live = mm_item_begin<WRITE_PRED>(it, Vmax, Km, s_S0[e], s_t, s_P, e * n_t, n_t, rtol, atol,
+                                                             pred_item);
+                            if (!live) {  // nothing to integrate: finished at once
+                                const bool ok = (it.i_out == n_t);
+                                a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
+                                a.info[out_idx] = ok ? 0 : (1 << 30);
+                            }
+                        } else {
+                            a.sum_r2[out_idx] = 0.0;
+                            a.info[out_idx] = 0;
+                            if (WRITE_PRED) {
+                                double *pp = a.pred + ((size_t)p * n_ex + e) * n_t;
+                                for (int i = 0; i < n_t; ++i) pp[i] = quiet_nan();
+                            }
+                        }
+                    }
+                }
+                q_lo += take;
+            }
+        }
+        if (__ballot(live) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+        if (live) {
+            const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
+            if (st != 0) {
+                const bool ok = (st == 1) && (it.i_out == n_t);
+                a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
+                a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
+                if (WRITE_PRED && !ok)
+                    for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
+                live = false;
+            }
         }
     }
-    const double sigma = mm.est_sigma ? th2 : mm.sigma_fixed;
-    const bool skip = !(sigma > 0.0) && !(sigma != sigma);  // sigma <= 0 -> -inf without solving (:53-54)
+}
 
-    if (valid && !skip) {
-        double *pred_pe = WRITE_PRED ? pred + ((size_t)p * n_ex + e) * n_t : nullptr;
-        MMSolveResult r = mm_solve_experiment<WRITE_PRED>(th0, th1, mm.S0[e], s_t + e * n_t, s_P + e * n_t, n_t,
-                                                          mm.rtol, mm.atol, pred_pe);
-        s_part[e * kWave + lane] = r.sum_r2;
-        s_flag[e * kWave + lane] = r.attempts | (r.failed << 30);
-    } else {
-        s_part[e * kWave + lane] = 0.0;
-        s_flag[e * kWave + lane] = 0;
-        if (WRITE_PRED && valid) {
-            double *pred_pe = pred + ((size_t)p * n_ex + e) * n_t;
-            for (int i = 0; i < n_t; ++i) pred_pe[i] = __longlong_as_double(0x7ff8000000000000LL);
-        }
-    }
-    __syncthreads();
-    if (e != 0) return;
-
-    // ---- wave 0: finish the particle ----
+// ---------------------------------------------------------------------------------------------
+// finish: logL from the per-experiment sums, then store or accept/select
+// ---------------------------------------------------------------------------------------------
+template <int MODE /*0 = likelihood only, 1 = MH accept/select*/>
+__global__ void __launch_bounds__(256)
+mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* evaluated point (proposal) */,
+                 int64_t stride, int64_t n, const double *__restrict__ sum_r2, const int *__restrict__ info,
+                 const uint8_t *__restrict__ p0_in, double *lk_io, double *filt, int64_t fstride,
+                 uint8_t *__restrict__ r_ac, SweepCounters *__restrict__ counters, double *__restrict__ dbg_lk2,
+                 uint8_t *__restrict__ dbg_r) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0;
-    if (valid) {
+    if (p < n) {
+        const int n_ex = mm.n_ex;
+        const double sigma = mm.est_sigma ? theta[2 * stride + p] : mm.sigma_fixed;
+        const bool masked = (MODE == 1) && (p0_in[p] == 0);
         double lk2;
-        if (skip) {
-            lk2 = -__longlong_as_double(0x7ff0000000000000LL);
+        if (masked) {
+            lk2 = lk_io[p];  // proposal was reset to the current point: the likelihood is the stored one
+        } else if (sigma <= 0.0) {
+            lk2 = -__longlong_as_double(0x7ff0000000000000LL);  // Micmem_likelihood.py:53-54
         } else {
             const double s2 = sigma * sigma;
-            const double c0 = (-0.5 * n_t) * log(2.0 * 3.141592653589793 * s2);  // :70
+            const double c0 = (-0.5 * mm.n_t) * log(2.0 * 3.141592653589793 * s2);  // :70
             lk2 = 0.0;
             for (int k = 0; k < n_ex; ++k) {
-                lk2 += c0 - s_part[k * kWave + lane] / (2.0 * s2);               // :70-73
-                const int fl = s_flag[k * kWave + lane];
+                lk2 += c0 - sum_r2[(int64_t)k * n + p] / (2.0 * s2);                // :70-73
+                const int fl = info[(int64_t)k * n + p];
                 attempts += (unsigned)(fl & 0x3fffffff);
                 failed |= (unsigned)(fl >> 30) & 1u;
             }
@@ -154,6 +244,7 @@ mm_sweep_kernel(MMModel mm, Prior prior, const double *theta_in /* may alias the
         } else {
             // ---- accept / select (:231-241) ----
             const double lk1 = lk_io[p];
+            const double p0 = masked ? 0.0 : 1.0;
             double rr;
             if (mh.device_rng) {
                 const u32x4 ru = philox_block(mh.seed, (uint64_t)(mh.global_offset + p), mh.stream,
@@ -166,32 +257,29 @@ mm_sweep_kernel(MMModel mm, Prior prior, const double *theta_in /* may alias the
             const double pp = exp(px * mh.gamma) * p0;
             const double r = (pp >= rr) ? 1.0 : 0.0;
             const double nr = 1.0 - r;
-            theta_filt[p] = __dadd_rn(__dmul_rn(th0, r), __dmul_rn(f0, nr));
-            theta_filt[stride + p] = __dadd_rn(__dmul_rn(th1, r), __dmul_rn(f1, nr));
-            theta_filt[2 * stride + p] = __dadd_rn(__dmul_rn(th2, r), __dmul_rn(f2, nr));
+            for (int c = 0; c < 3; ++c) {
+                const double th = theta[c * stride + p], f = filt[c * fstride + p];
+                filt[c * fstride + p] = __dadd_rn(__dmul_rn(th, r), __dmul_rn(f, nr));
+            }
             lk_io[p] = __dadd_rn(__dmul_rn(lk2, r), __dmul_rn(lk1, nr));
             const uint8_t ever = (uint8_t)(r_ac[p] | (uint8_t)(r != 0.0));
             r_ac[p] = ever;
             acc_now = (r != 0.0);
             acc_ever = ever;
-            if (dbg_prop) {
-                dbg_prop[p] = th0;
-                dbg_prop[n + p] = th1;
-                dbg_prop[2 * n + p] = th2;
+            if (dbg_lk2) {
                 dbg_lk2[p] = lk2;
-                dbg_p0[p] = (uint8_t)(p0 != 0.0);
                 dbg_r[p] = (uint8_t)(r != 0.0);
             }
         }
     }
-    // wave-level integer reductions, then one atomic per block and counter
+    // integer reductions: wave shuffles, then one atomic per wave and counter (order-independent)
     for (int off = 32; off > 0; off >>= 1) {
         attempts += __shfl_down(attempts, off);
         failed += __shfl_down(failed, off);
         acc_now += __shfl_down(acc_now, off);
         acc_ever += __shfl_down(acc_ever, off);
     }
-    if (lane == 0) {
+    if ((threadIdx.x & 63) == 0) {
         if (attempts) atomicAdd(&counters->rk_attempts, attempts);
         if (failed) atomicAdd(&counters->n_failed, failed);
         if (MODE == 1) {
@@ -201,34 +289,62 @@ mm_sweep_kernel(MMModel mm, Prior prior, const double *theta_in /* may alias the
     }
 }
 
-static size_t sweep_lds_bytes(const MMModel &mm) {
-    return (size_t)(2 * mm.n_ex * mm.n_t + mm.n_ex * kWave) * sizeof(double) + (size_t)mm.n_ex * kWave * sizeof(int);
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred) {
+    const MMModel &mm = ctx->mm;
+    SolveArgs a{};
+    a.theta = theta;
+    a.stride = stride;
+    a.n = n;
+    a.p0 = p0;
+    a.sum_r2 = ctx->d_sum_r2;
+    a.info = ctx->d_info;
+    a.pred = pred;
+    a.queue = ctx->d_queue;
+    (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
+    const size_t lds = (size_t)(2 * mm.n_ex * mm.n_t + mm.n_ex) * sizeof(double);
+    // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more blocks than chunks
+    const int64_t chunks = (((n + kWave - 1) / kWave) * kWave * mm.n_ex + kChunk - 1) / kChunk;
+    int64_t blocks = (int64_t)ctx->cu_count * ctx->solve_blocks_per_cu;
+    const int64_t need = (chunks + (kSolveBlock / kWave) - 1) / (kSolveBlock / kWave);
+    if (blocks > need) blocks = need;
+    if (blocks < 1) blocks = 1;
+    ScopedTimer tm(ctx, SMC_T_SOLVE);
+    if (pred)
+        hipLaunchKernelGGL((mm_solve_kernel<true>), dim3((unsigned)blocks), dim3(kSolveBlock), lds, ctx->stream, mm, a);
+    else
+        hipLaunchKernelGGL((mm_solve_kernel<false>), dim3((unsigned)blocks), dim3(kSolveBlock), lds, ctx->stream, mm, a);
 }
 
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred) {
     if (n <= 0) return;
-    const MMModel &mm = ctx->mm;
-    dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave * mm.n_ex);
+    launch_solve(ctx, theta, stride, n, nullptr, pred);
     MHParams mh{};
-    const size_t lds = sweep_lds_bytes(mm);
-    if (pred)
-        hipLaunchKernelGGL((mm_sweep_kernel<0, true>), grid, block, lds, ctx->stream, mm, ctx->prior, theta, stride, n,
-                           lk, pred, mh, nullptr, nullptr, ctx->d_counters, nullptr, nullptr, nullptr, nullptr);
-    else
-        hipLaunchKernelGGL((mm_sweep_kernel<0, false>), grid, block, lds, ctx->stream, mm, ctx->prior, theta, stride, n,
-                           lk, nullptr, mh, nullptr, nullptr, ctx->d_counters, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((mm_finish_kernel<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->mm, mh,
+                       theta, stride, n, ctx->d_sum_r2, ctx->d_info, nullptr, lk, nullptr, 0, nullptr, ctx->d_counters,
+                       nullptr, nullptr);
 }
 
 void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
     if (n <= 0) return;
-    const MMModel &mm = ctx->mm;
-    dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave * mm.n_ex);
-    const size_t lds = sweep_lds_bytes(mm);
     ParticleSet &F = ctx->set[SMC_SET_FILT];
+    ParticleSet &P = ctx->set[SMC_SET_PRED];  // receives the proposals, as the reference's p_pred does (:220,228)
     const bool dbg = ctx->debug_capture != 0;
-    hipLaunchKernelGGL((mm_sweep_kernel<1, false>), grid, block, lds, ctx->stream, mm, ctx->prior, F.theta, F.stride, n,
-                       F.lk, nullptr, mh, F.theta, ctx->r_ac, ctx->d_counters, dbg ? ctx->dbg_prop : nullptr,
-                       dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_p0 : nullptr, dbg ? ctx->dbg_r : nullptr);
+    hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
+                       F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
+    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr);
+    hipLaunchKernelGGL((mm_finish_kernel<1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->mm, mh,
+                       P.theta, P.stride, n, ctx->d_sum_r2, ctx->d_info, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac,
+                       ctx->d_counters, dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);
+}
+
+int query_solve_blocks_per_cu() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false>, kSolveBlock, 4096) != hipSuccess || nb < 1)
+        nb = 2;
+    return nb;
 }
 
 }  // namespace smc

@@ -87,6 +87,8 @@ static void timing_collect(smc_ctx *c) {
     c->ev_used.clear();
 }
 
+static int ensure_item_capacity(smc_ctx *c, int64_t n);
+
 extern "C" {
 
 int smc_abi_version(void) { return SMC_ABI_VERSION; }
@@ -130,6 +132,14 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->r_ac, (size_t)n_local));
     CK(hipMemsetAsync(c->r_ac, 0, (size_t)n_local, c->stream));
     CK(hipMalloc(&c->d_counters, sizeof(SweepCounters)));
+    CK(hipMalloc(&c->d_queue, sizeof(unsigned long long)));
+    CK(hipMalloc(&c->d_p0, (size_t)n_local));
+    {
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, device));
+        c->cu_count = prop.multiProcessorCount;
+        c->solve_blocks_per_cu = query_solve_blocks_per_cu();
+    }
     CK(hipHostMalloc(&c->h_counters, sizeof(SweepCounters)));
     CK(hipMalloc(&c->d_noise, nb * (dim + 1)));
     c->d_rr = c->d_noise + (size_t)n_local * dim;
@@ -180,10 +190,12 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_blk_r);
     (void)hipFree(c->d_blk_c);
     (void)hipFree(c->d_sendbuf);
-    (void)hipFree(c->dbg_prop);
     (void)hipFree(c->dbg_lk2);
-    (void)hipFree(c->dbg_p0);
     (void)hipFree(c->dbg_r);
+    (void)hipFree(c->d_sum_r2);
+    (void)hipFree(c->d_info);
+    (void)hipFree(c->d_p0);
+    (void)hipFree(c->d_queue);
     (void)hipFree(c->d_hb_theta);
     (void)hipFree(c->d_hb_lk);
     (void)hipFree(c->d_hb_pred);
@@ -239,8 +251,9 @@ int smc_set_model_mm(smc_ctx *c, const double *t, const double *P_obs, const dou
     c->mm.sigma_fixed = sigma_fixed;
     c->mm.rtol = rtol;
     c->mm.atol = atol;
+    c->item_cap = 0;  // per-(experiment, particle) scratch is sized by n_ex
     c->have_model = true;
-    return 0;
+    return ensure_item_capacity(c, c->n_local);
 }
 
 int smc_set_prior(smc_ctx *c, const int *kind, const double *a, const double *b, int dim) {
@@ -327,6 +340,19 @@ int smc_sample_prior_device(smc_ctx *c, uint64_t seed, int64_t global_offset) {
 }
 
 // ---- sweeps --------------------------------------------------------------------------------------
+static int ensure_item_capacity(smc_ctx *c, int64_t n) {
+    if (n <= c->item_cap) return 0;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_sum_r2);
+    (void)hipFree(c->d_info);
+    c->d_sum_r2 = nullptr;
+    c->d_info = nullptr;
+    c->item_cap = 0;
+    HIPC(c, hipMalloc(&c->d_sum_r2, (size_t)n * c->mm.n_ex * sizeof(double)));
+    HIPC(c, hipMalloc(&c->d_info, (size_t)n * c->mm.n_ex * sizeof(int)));
+    c->item_cap = n;
+    return 0;
+}
 static int counters_begin(smc_ctx *c) {
     HIPC(c, hipMemsetAsync(c->d_counters, 0, sizeof(SweepCounters), c->stream));
     return 0;
@@ -379,6 +405,7 @@ int smc_mm_loglik_host(smc_ctx *c, const double *particle, int64_t n, double *lk
         HIPC(c, hipMalloc(&c->d_hb_pred, (size_t)n * per * sizeof(double)));
         c->hb_pred_cap = n;
     }
+    if (ensure_item_capacity(c, n)) return 1;
     double *aos = c->d_hb_theta, *soa = c->d_hb_theta + (size_t)c->hb_cap * 3;
     HIPC(c, hipMemcpyAsync(aos, particle, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     launch_aos_to_soa(c, aos, soa, n, 3, n);
@@ -660,11 +687,9 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
 int smc_set_debug_capture(smc_ctx *c, int enable) {
     if (!c) return fail(nullptr, "NULL context");
     HIPC(c, hipSetDevice(c->device));
-    if (enable && !c->dbg_prop) {
+    if (enable && !c->dbg_lk2) {
         const size_t n = (size_t)c->n_local;
-        HIPC(c, hipMalloc(&c->dbg_prop, n * c->dim * sizeof(double)));
         HIPC(c, hipMalloc(&c->dbg_lk2, n * sizeof(double)));
-        HIPC(c, hipMalloc(&c->dbg_p0, n));
         HIPC(c, hipMalloc(&c->dbg_r, n));
     }
     c->debug_capture = enable;
@@ -672,12 +697,13 @@ int smc_set_debug_capture(smc_ctx *c, int enable) {
 }
 int smc_download_debug_proposals(smc_ctx *c, double *aos, double *lk2, uint8_t *p0, uint8_t *r, int64_t n) {
     if (check_set(c, SMC_SET_FILT, n)) return 1;
-    if (!c->dbg_prop) return fail(c, "debug capture is not enabled");
+    if (!c->dbg_lk2) return fail(c, "debug capture is not enabled");
     HIPC(c, hipSetDevice(c->device));
-    launch_soa_to_aos(c, c->dbg_prop, c->d_stage, n, c->dim, c->n_local);
+    // the proposals of the last MH iteration are what SMC_SET_PRED holds (the reference's p_pred, :220,228)
+    launch_soa_to_aos(c, c->set[SMC_SET_PRED].theta, c->d_stage, n, c->dim, c->set[SMC_SET_PRED].stride);
     HIPC(c, hipMemcpyAsync(aos, c->d_stage, (size_t)n * c->dim * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipMemcpyAsync(lk2, c->dbg_lk2, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPC(c, hipMemcpyAsync(p0, c->dbg_p0, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(p0, c->d_p0, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipMemcpyAsync(r, c->dbg_r, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;

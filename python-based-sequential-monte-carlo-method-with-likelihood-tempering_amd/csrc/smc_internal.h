@@ -91,10 +91,18 @@ struct smc_ctx {
     int64_t n_tiles = 0;
     double *d_sendbuf = nullptr;     // (d+1) x capacity staging for remote offspring
     int64_t sendbuf_cap = 0;
-    // debug capture of the last MH proposals
+    // sweep scratch: per (experiment, particle) sums of squared residuals and solver info, support
+    // flags of the proposals, the global work counter of the persistent solve kernel
+    double *d_sum_r2 = nullptr;
+    int *d_info = nullptr;
+    int64_t item_cap = 0;            // particles the two arrays above can hold (x kMaxEx experiments)
+    uint8_t *d_p0 = nullptr;
+    unsigned long long *d_queue = nullptr;
+    int cu_count = 0, solve_blocks_per_cu = 0;
+    // debug capture of the last MH iteration (lk2, accept flags; proposals live in SMC_SET_PRED)
     int debug_capture = 0;
-    double *dbg_prop = nullptr, *dbg_lk2 = nullptr;
-    uint8_t *dbg_p0 = nullptr, *dbg_r = nullptr;
+    double *dbg_lk2 = nullptr;
+    uint8_t *dbg_r = nullptr;
     // host batch sweeps (drop-in sim_particle)
     double *d_hb_theta = nullptr, *d_hb_lk = nullptr, *d_hb_pred = nullptr;
     int64_t hb_cap = 0, hb_pred_cap = 0;
@@ -116,6 +124,7 @@ namespace smc {
 // kernel launchers implemented in mm_kernels.hip
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred);
 void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
+int query_solve_blocks_per_cu();
 
 struct ScopedTimer {
     smc_ctx *c;
