@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -724,7 +725,9 @@ int smc_comm_init(smc_ctx *c, const uint8_t id[128], int rank, int world) {
     HIPC(c, hipSetDevice(c->device));
     c->rank = rank;
     c->world = world;
-    if (world == 1) return 0;
+    // a single rank needs no communicator; SMC_FORCE_RCCL=1 creates one anyway so that the RCCL call
+    // sequence can be exercised on a one-GPU machine
+    if (world == 1 && !getenv("SMC_FORCE_RCCL")) return 0;
     ncclUniqueId u;
     memcpy(&u, id, 128);
     ncclComm_t comm;
@@ -738,7 +741,10 @@ template <typename T>
 static int allreduce_impl(smc_ctx *c, T *inout, int n, ncclDataType_t dt, ncclRedOp_t op) {
     if (!c) return fail(nullptr, "NULL context");
     if (n < 0 || (size_t)n * sizeof(T) > 4096 * sizeof(double)) return fail(c, "collective payload too large");
-    if (c->world == 1 || n == 0) return 0;
+    if (!c->nccl_comm || n == 0) {
+        if (c->world > 1) return fail(c, "smc_comm_init has not been called");
+        return 0;
+    }
     HIPC(c, hipSetDevice(c->device));
     memcpy(c->h_small, inout, (size_t)n * sizeof(T));
     HIPC(c, hipMemcpyAsync(c->d_small, c->h_small, (size_t)n * sizeof(T), hipMemcpyHostToDevice, c->stream));
@@ -758,7 +764,8 @@ template <typename T>
 static int allgather_impl(smc_ctx *c, const T *in, int n, T *out, ncclDataType_t dt) {
     if (!c) return fail(nullptr, "NULL context");
     if (n < 0 || (size_t)n * c->world * sizeof(T) > 2048 * sizeof(double)) return fail(c, "collective payload too large");
-    if (c->world == 1) {
+    if (!c->nccl_comm) {
+        if (c->world > 1) return fail(c, "smc_comm_init has not been called");
         memcpy(out, in, (size_t)n * sizeof(T));
         return 0;
     }

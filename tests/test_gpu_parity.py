@@ -425,3 +425,22 @@ def test_errors_are_reported(pkg, data):
             eng.upload_particles(pkg.SMC_SET_PRED, np.zeros((11, 3)))   # exceeds capacity
     with pytest.raises(pkg.SmcError):
         pkg.HipEngine(10, 3, device=99)
+
+
+def test_rccl_call_sequence_single_rank(pkg, data, golden_run, monkeypatch):
+    """The RCCL communicator path (ncclCommInitRank, allreduce / allgather on device scratch) with one
+    rank: the collectives must be the identity and the full run must equal the reference run."""
+    monkeypatch.setenv("SMC_FORCE_RCCL", "1")
+    g = golden_run
+    with make_engine(pkg, data, 1000) as eng:
+        comm = pkg.RcclComm(eng, 0, 1, lambda uid: uid)
+        assert np.array_equal(comm.allreduce_sum([1.5, -2.0, 3.25]), [1.5, -2.0, 3.25])
+        assert np.array_equal(comm.allreduce_max([7.0]), [7.0])
+        assert np.array_equal(comm.allreduce_sum_i64([5, 6]), [5, 6])
+        assert np.array_equal(comm.allgather([1.0, 2.0]), [[1.0, 2.0]])
+        assert np.array_equal(comm.allgather_i64([9]), [[9]])
+        comm.barrier()
+        out = pkg.run_smc(eng, pkg.SMCSettings(), comm=comm, rng="numpy", verbose=False)
+    assert np.array_equal([r["gamma_new"] for r in out["records"]], g["sched_gamma"])
+    assert np.array_equal([r["n_accept"] for r in out["records"]], g["sched_accept"])
+    assert np.abs(out["p_pred"] - g["final_p_pred"]).max() < 1e-9
