@@ -74,7 +74,7 @@ __device__ __forceinline__ double quiet_nan() { return __longlong_as_double(0x7f
 // inverse fifth root: x = m * 2^e with m in [0.5,1), e = 5q + r;  x^-0.2 = m^-0.2 * 2^(-r/5) * 2^-q.
 // m^-0.2 starts from the hardware f32 log2/exp2 (about 22 good bits) and takes two Newton steps
 // y <- y + y*(1 - m*y^5)/5 in FP64 (quadratic convergence: 22 -> 42 -> >53 bits).  Error <= 2 ulp,
-// the same class as the libm-vs-device pow difference it replaces (the oracle keeps libm pow).
+// the same class as the libm-vs-device pow difference it replaces (the CPU checker under tests keeps libm pow).
 __device__ __forceinline__ double pow_minus_fifth(double x) {
     if (!(x > 0.0)) return (x == 0.0) ? __longlong_as_double(0x7ff0000000000000LL) : quiet_nan();  // 0 -> inf
     if (x == __longlong_as_double(0x7ff0000000000000LL)) return 0.0;
