@@ -189,10 +189,23 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                 q_lo += take;
             }
         }
-        if (__ballot(live) == 0ull) {
-            if (drained) break;
-            continue;
+        if (drained) {
+            // tail: no item is left to hand out.  What remains are the long serial chains of stiff items;
+            // run each lane's item to completion in a tight per-lane loop (no ballots, no refill logic).
+            if (live) {
+                int st;
+                do {
+                    st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
+                } while (st == 0);
+                const bool ok = (st == 1) && (it.i_out == n_t);
+                a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
+                a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
+                if (WRITE_PRED && !ok)
+                    for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
+            }
+            break;
         }
+        if (__ballot(live) == 0ull) continue;
         if (live) {
             const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
             if (st != 0) {
@@ -217,9 +230,10 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                  const uint8_t *__restrict__ p0_in, double *lk_io, double *filt, int64_t fstride,
                  uint8_t *__restrict__ r_ac, SweepCounters *__restrict__ counters, double *__restrict__ dbg_lk2,
                  uint8_t *__restrict__ dbg_r) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long s_cnt[4][4];
     unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0;
-    if (p < n) {
+    // grid-stride: a few hundred blocks, so that the counters cost one atomic per block, not per wave
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const int n_ex = mm.n_ex;
         const double sigma = mm.est_sigma ? theta[2 * stride + p] : mm.sigma_fixed;
         const bool masked = (MODE == 1) && (p0_in[p] == 0);
@@ -232,12 +246,14 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
             const double s2 = sigma * sigma;
             const double c0 = (-0.5 * mm.n_t) * log(2.0 * 3.141592653589793 * s2);  // :70
             lk2 = 0.0;
+            unsigned pf = 0;
             for (int k = 0; k < n_ex; ++k) {
                 lk2 += c0 - sum_r2[(int64_t)k * n + p] / (2.0 * s2);                // :70-73
                 const int fl = info[(int64_t)k * n + p];
                 attempts += (unsigned)(fl & 0x3fffffff);
-                failed |= (unsigned)(fl >> 30) & 1u;
+                pf |= (unsigned)(fl >> 30) & 1u;
             }
+            failed += pf;
         }
         if (MODE == 0) {
             lk_io[p] = lk2;
@@ -264,34 +280,47 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
             lk_io[p] = __dadd_rn(__dmul_rn(lk2, r), __dmul_rn(lk1, nr));
             const uint8_t ever = (uint8_t)(r_ac[p] | (uint8_t)(r != 0.0));
             r_ac[p] = ever;
-            acc_now = (r != 0.0);
-            acc_ever = ever;
+            acc_now += (r != 0.0);
+            acc_ever += ever;
             if (dbg_lk2) {
                 dbg_lk2[p] = lk2;
                 dbg_r[p] = (uint8_t)(r != 0.0);
             }
         }
     }
-    // integer reductions: wave shuffles, then one atomic per wave and counter (order-independent)
+    // integer reductions (order-independent): wave shuffles, LDS across the 4 waves, one atomic per block
     for (int off = 32; off > 0; off >>= 1) {
         attempts += __shfl_down(attempts, off);
         failed += __shfl_down(failed, off);
         acc_now += __shfl_down(acc_now, off);
         acc_ever += __shfl_down(acc_ever, off);
     }
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        if (attempts) atomicAdd(&counters->rk_attempts, attempts);
-        if (failed) atomicAdd(&counters->n_failed, failed);
-        if (MODE == 1) {
-            if (acc_now) atomicAdd(&counters->accepted_now, acc_now);
-            if (acc_ever) atomicAdd(&counters->accepted_ever, acc_ever);
-        }
+        s_cnt[w][0] = attempts;
+        s_cnt[w][1] = failed;
+        s_cnt[w][2] = acc_now;
+        s_cnt[w][3] = acc_ever;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const unsigned long long v = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] +
+                                     s_cnt[3][threadIdx.x];
+        unsigned long long *dst = threadIdx.x == 0 ? &counters->rk_attempts
+                                  : threadIdx.x == 1 ? &counters->n_failed
+                                  : threadIdx.x == 2 ? &counters->accepted_now : &counters->accepted_ever;
+        if (v) atomicAdd(dst, v);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+static unsigned finish_grid(int64_t n) {
+    const int64_t g = (n + 255) / 256;
+    return (unsigned)(g < 1024 ? (g < 1 ? 1 : g) : 1024);
+}
+
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
@@ -322,7 +351,7 @@ void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t
     if (n <= 0) return;
     launch_solve(ctx, theta, stride, n, nullptr, pred);
     MHParams mh{};
-    hipLaunchKernelGGL((mm_finish_kernel<0>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->mm, mh,
+    hipLaunchKernelGGL((mm_finish_kernel<0>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        theta, stride, n, ctx->d_sum_r2, ctx->d_info, nullptr, lk, nullptr, 0, nullptr, ctx->d_counters,
                        nullptr, nullptr);
 }
@@ -335,7 +364,7 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
     launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr);
-    hipLaunchKernelGGL((mm_finish_kernel<1>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->mm, mh,
+    hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        P.theta, P.stride, n, ctx->d_sum_r2, ctx->d_info, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac,
                        ctx->d_counters, dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);
 }

@@ -55,9 +55,31 @@ namespace smc {
 
 #define RK_MAX_ATTEMPTS (1 << 20)  // hard bound so that every wave drains; SciPy has none
 
-__device__ __forceinline__ double mm_rhs(double S, double negVmax, double Km) {
-    return (negVmax * S) / (Km + S);  // ((-Vmax)*S)/(Km+S), Micmem_likelihood.py:15
+// a / b with a shorter dependent chain than the compiler's IEEE sequence (v_div_scale, v_rcp, two
+// Newton steps, v_div_fmas, v_div_fixup: ~30 ns on the chain vs 18 ns here).  v_rcp_f64 is accurate to
+// 2^-24.4 (measured, tools/div_probe.hip), so ONE Newton step gives 2^-48.8 and the Markstein
+// correction q + (a - b*q)*r rounds correctly: bit-identical to a/b on 4M random operands.  It has no
+// scaling and no special-case fix-up, so it is only used inside rk_attempt_core<true>, whose caller
+// re-runs the whole attempt with IEEE division whenever the result is not finite; quotients in the
+// denormal range may differ from IEEE in the last bits (they sit > 280 orders below atol).
+__device__ __forceinline__ double lean_div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    const double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    const double q = a * r;
+    const double rem = fma(-b, q, a);
+    return fma(rem, r, q);
 }
+template <bool LEAN>
+__device__ __forceinline__ double mm_div(double a, double b) {
+    return LEAN ? lean_div(a, b) : a / b;
+}
+template <bool LEAN>
+__device__ __forceinline__ double mm_rhs_t(double S, double negVmax, double Km) {
+    return mm_div<LEAN>(negVmax * S, Km + S);  // ((-Vmax)*S)/(Km+S), Micmem_likelihood.py:15
+}
+__device__ __forceinline__ double mm_rhs(double S, double negVmax, double Km) { return mm_rhs_t<false>(S, negVmax, Km); }
+
 // Python's min(a,b)/max(a,b): keep a unless b is strictly better (NaN never is)
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
 __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
@@ -69,36 +91,32 @@ __device__ __forceinline__ double min_step_of(double t) {
 __device__ __forceinline__ double quiet_nan() { return __longlong_as_double(0x7ff8000000000000LL); }
 
 // x ** -0.2 for x >= 0 (the step-size controller's error_norm ** error_exponent, rk.py:104,155,169).
-// The generic pow() is ~200 dependent FP64 instructions - half of a whole RK45 attempt and therefore
-// half of the serial critical path of a stiff solve (10^5 dependent attempts).  This is a dedicated
-// inverse fifth root: x = m * 2^e with m in [0.5,1), e = 5q + r;  x^-0.2 = m^-0.2 * 2^(-r/5) * 2^-q.
-// m^-0.2 starts from the hardware f32 log2/exp2 (about 22 good bits) and takes two Newton steps
-// y <- y + y*(1 - m*y^5)/5 in FP64 (quadratic convergence: 22 -> 42 -> >53 bits).  Error <= 2 ulp,
-// the same class as the libm-vs-device pow difference it replaces (the CPU checker under tests keeps libm pow).
+// The generic pow() costs 352 ns on the dependent chain of an attempt (measured, tools/div_probe.hip) -
+// nearly half of it - and that chain is the serial critical path of a stiff solve (up to 10^5 dependent
+// attempts).  Dedicated inverse fifth root: seed y0 = exp2(-0.2*log2(x)) from the hardware f32
+// transcendentals (relative error <= 2^-20 for 2^-64 < x < 2^64), then ONE third-order correction
+//   rho = 1 - x*y^5,   y <- y + y*rho*(1/5 + (3/25)*rho)      [ (1-rho)^(-1/5) = 1 + rho/5 + 3rho^2/25 + ... ]
+// whose truncation error 0.09*rho^3 <= 2^-58.  Result within ~1.5 ulp - the same class as the
+// libm-vs-device pow difference it replaces (the CPU checker under tests keeps libm pow).  Arguments
+// outside the window are reduced first: x = m*2^e, e = 5q + r, m*2^r in [0.5, 16).
+__device__ __forceinline__ double pow_minus_fifth_core(double x) {
+    const float lf = __builtin_amdgcn_logf((float)x);                 // v_log_f32: log2
+    const double y = (double)__builtin_amdgcn_exp2f(-0.2f * lf);      // v_exp_f32
+    const double y2 = y * y;
+    const double y5 = (y2 * y2) * y;
+    const double rho = fma(-x, y5, 1.0);
+    return fma(y * rho, fma(0.12, rho, 0.2), y);
+}
 __device__ __forceinline__ double pow_minus_fifth(double x) {
+    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0xfffu;  // sign + biased exponent
+    if (__builtin_expect((e - 959u) < 128u, 1)) return pow_minus_fifth_core(x);   // 2^-64 <= x < 2^64
     if (!(x > 0.0)) return (x == 0.0) ? __longlong_as_double(0x7ff0000000000000LL) : quiet_nan();  // 0 -> inf
     if (x == __longlong_as_double(0x7ff0000000000000LL)) return 0.0;
     const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
-    const int e = __builtin_amdgcn_frexp_exp(x);
-    // floor division of e by 5 (e in [-1073, 1024]):  (e + 1075) / 5 - 215
-    const int q = (e + 1075) / 5 - 215;
-    const int r = e - 5 * q;                            // 0..4
-    const float lf = __builtin_amdgcn_logf((float)m);   // log2(m), v_log_f32
-    double y = (double)__builtin_amdgcn_exp2f(-0.2f * lf);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const double y2 = y * y;
-        const double y5 = (y2 * y2) * y;
-        const double rho = fma(-m, y5, 1.0);
-        y = fma(y * 0.2, rho, y);
-    }
-    // 2^(-r/5)
-    double c = 1.0;
-    c = (r == 1) ? 0.87055056329612413913627001747975 : c;
-    c = (r == 2) ? 0.75785828325519900315210303617030 : c;
-    c = (r == 3) ? 0.65975395538644709660394940471556 : c;
-    c = (r == 4) ? 0.57434917749851750271711478780370 : c;
-    return ldexp(y * c, -q);
+    const int ex = __builtin_amdgcn_frexp_exp(x);
+    const int q = (ex + 1075) / 5 - 215;               // floor(ex / 5), ex in [-1073, 1024]
+    const int r = ex - 5 * q;                          // 0..4
+    return ldexp(pow_minus_fifth_core(ldexp(m, r)), -q);
 }
 
 // Live state of one lane's current item.  common.py:63-65: the RMS norm of a size-1 vector is
@@ -172,56 +190,68 @@ __device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km
     return true;
 }
 
+// rk_step (rk.py:64-71, stages summed left to right) + error norm (rk.py:106-110,146-147; np.maximum
+// propagates NaN) of one attempt: a pure function of the lane's state.
+struct RkStages {
+    double k1, k2, k3, k4, k5, k6, y_new, error_norm;
+};
+template <bool LEAN>
+__device__ __forceinline__ RkStages rk_attempt_core(double y, double k0, double h, double negVmax, double Km,
+                                                    double rtol, double atol) {
+    RkStages s;
+    s.k1 = mm_rhs_t<LEAN>(y + (k0 * A21) * h, negVmax, Km);
+    s.k2 = mm_rhs_t<LEAN>(y + (k0 * A31 + s.k1 * A32) * h, negVmax, Km);
+    s.k3 = mm_rhs_t<LEAN>(y + (k0 * A41 + s.k1 * A42 + s.k2 * A43) * h, negVmax, Km);
+    s.k4 = mm_rhs_t<LEAN>(y + (k0 * A51 + s.k1 * A52 + s.k2 * A53 + s.k3 * A54) * h, negVmax, Km);
+    s.k5 = mm_rhs_t<LEAN>(y + (k0 * A61 + s.k1 * A62 + s.k2 * A63 + s.k3 * A64 + s.k4 * A65) * h, negVmax, Km);
+    s.y_new = y + h * (k0 * B1 + s.k2 * B3 + s.k3 * B4 + s.k4 * B5 + s.k5 * B6);
+    s.k6 = mm_rhs_t<LEAN>(s.y_new, negVmax, Km);
+    const double ay = fabs(y), ayn = fabs(s.y_new);
+    const double scale = atol + ((ay > ayn || ay != ay) ? ay : ayn) * rtol;
+    const double err = (k0 * E1 + s.k2 * E3 + s.k3 * E4 + s.k4 * E5 + s.k5 * E6 + s.k6 * E7) * h;
+    s.error_norm = fabs(mm_div<LEAN>(err, scale));
+    return s;
+}
+
 // One step attempt.  Returns 0 while the item is still running, 1 when it finished (t reached
 // t_bound), 2 when it failed (step size underflow, rk.py:133-134; SciPy status -1).
 template <bool WRITE_PRED>
 __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, const double *s_P, int n_t, double rtol,
                                                double atol, double *pred) {
-    if (it.h_abs < it.min_step || it.attempts >= RK_MAX_ATTEMPTS) return 2;
+    // rk.py:133-134 TOO_SMALL_STEP (plus the hard attempt bound): tested together with the other rare
+    // conditions in the single branch below; the stages computed meanwhile are simply discarded
+    const bool fail = it.h_abs < it.min_step || it.attempts >= RK_MAX_ATTEMPTS;
     const double t = it.t, y = it.y, negVmax = it.negVmax, Km = it.Km;
     double t_new = t + it.h_abs;
     if (t_new - it.t_bound > 0) t_new = it.t_bound;
     const double h = t_new - t;
     it.h_abs = fabs(h);
 
-    // ---- rk_step (rk.py:64-71), stages summed left to right ----
     const double k0 = it.f;
-    const double k1 = mm_rhs(y + (k0 * A21) * h, negVmax, Km);
-    const double k2 = mm_rhs(y + (k0 * A31 + k1 * A32) * h, negVmax, Km);
-    const double k3 = mm_rhs(y + (k0 * A41 + k1 * A42 + k2 * A43) * h, negVmax, Km);
-    const double k4 = mm_rhs(y + (k0 * A51 + k1 * A52 + k2 * A53 + k3 * A54) * h, negVmax, Km);
-    const double k5 = mm_rhs(y + (k0 * A61 + k1 * A62 + k2 * A63 + k3 * A64 + k4 * A65) * h, negVmax, Km);
-    const double y_new = y + h * (k0 * B1 + k2 * B3 + k3 * B4 + k4 * B5 + k5 * B6);
-    const double k6 = mm_rhs(y_new, negVmax, Km);
+    RkStages st = rk_attempt_core<true>(y, k0, h, negVmax, Km, rtol, atol);
     ++it.attempts;
 
-    // ---- error norm (rk.py:106-110,146-147); np.maximum propagates NaN ----
-    const double ay = fabs(y), ayn = fabs(y_new);
-    const double scale = atol + ((ay > ayn || ay != ay) ? ay : ayn) * rtol;
-    const double err = (k0 * E1 + k2 * E3 + k3 * E4 + k4 * E5 + k5 * E6 + k6 * E7) * h;
-    const double error_norm = fabs(err / scale);
-
-    // 0.9 * error_norm ** -0.2, needed by both branches of rk.py:149-171 (error_norm == 0 gives inf,
-    // which min(MAX_FACTOR, .) turns into MAX_FACTOR exactly as the reference's special case does)
-    const double pw = 0.9 * pow_minus_fifth(error_norm);
-
-    if (!(error_norm < 1.0)) {
-        it.h_abs *= py_max(0.2, pw);
-        it.rejected = true;
-        return 0;
-    }
-    double factor = py_min(10.0, pw);
-    if (it.rejected) factor = py_min(1.0, factor);
-    it.h_abs *= factor;
-
+    // 0.9 * error_norm ** -0.2 is needed by both branches of rk.py:149-171 (error_norm == 0 gives inf,
+    // which min(MAX_FACTOR, .) turns into MAX_FACTOR exactly as the reference's special case does).
+    // Accept / reject is written with selects, not branches: on the serial chain of a stiff solve every
+    // vector-compare -> scalar-branch round trip costs as much as several FP64 operations.  The one
+    // branch below covers both the rare IEEE re-run and the dense output.
+    double pw = 0.9 * pow_minus_fifth(st.error_norm);
+    bool accept = st.error_norm < 1.0;
+    const bool redo = !(st.error_norm <= 1.7976931348623157e308);   // NaN / inf from the lean division
     const double t_old = t, y_old = y;
-    it.t = t_new;
-    it.y = y_new;
-    it.f = k6;
-
-    // ---- outputs with t_eval in (t_old, t] (ivp.py:700-720) by the quartic interpolant ----
-    if (it.t_next <= t_new) {
-        int i_out = it.i_out;
+    if (fail || redo || (accept && it.t_next <= t_new)) {
+        if (fail) return 2;
+        if (redo) {
+            st = rk_attempt_core<false>(y, k0, h, negVmax, Km, rtol, atol);
+            pw = 0.9 * pow_minus_fifth(st.error_norm);
+            accept = st.error_norm < 1.0;
+        }
+        if (accept && it.t_next <= t_new) {
+            // ---- outputs with t_eval in (t_old, t] (ivp.py:700-720) by the quartic interpolant ----
+            const double k1 = st.k1, k2 = st.k2, k3 = st.k3, k4 = st.k4, k5 = st.k5, k6 = st.k6;
+            (void)k1;
+            int i_out = it.i_out;
         const int base = it.t_off;
         double t_next = it.t_next;
         // Q = K.T.dot(P) (rk.py:179); P[1][:] = 0 and P[j][0] = 0 for j > 0
@@ -251,12 +281,21 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, co
         it.sum_r2 = sum_r2;
         it.i_out = i_out;
         it.t_next = t_next;
+        }
     }
-    if (t_new - it.t_bound >= 0) return 1;  // base.py:196
-    it.rejected = false;                    // head of the next _step_impl
-    it.min_step = min_step_of(t_new);
-    if (it.h_abs < it.min_step) it.h_abs = it.min_step;
-    return 0;
+    double fac_acc = py_min(10.0, pw);
+    fac_acc = it.rejected ? py_min(1.0, fac_acc) : fac_acc;
+    const double fac_rej = py_max(0.2, pw);
+    it.h_abs *= accept ? fac_acc : fac_rej;
+    it.rejected = !accept;
+    it.t = accept ? t_new : t;
+    it.y = accept ? st.y_new : y;
+    it.f = accept ? st.k6 : k0;
+    // head of the next _step_impl (rk.py:120-127) after an accepted step; after a rejection t, hence
+    // min_step, is unchanged and the reference only re-tests h_abs < min_step (top of this function)
+    it.min_step = min_step_of(it.t);
+    it.h_abs = (accept && it.h_abs < it.min_step) ? it.min_step : it.h_abs;
+    return (accept && (t_new - it.t_bound >= 0)) ? 1 : 0;  // base.py:196
 }
 
 }  // namespace smc
