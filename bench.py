@@ -138,6 +138,28 @@ def main():
     timing = eng.timing_get()
     eng.timing_enable(False)
 
+    # steady state (outside the timed region): Metropolis sweeps at gamma = 1 on the final, posterior
+    # population - the regime SURVEY.md 8(d) calls "posterior-like"; no stiff stragglers left
+    steady = None
+    if world == 1:
+        eng.timing_enable(True)
+        eng.timing_reset()
+        eng.upload_particles(pkg.SMC_SET_FILT, outs[-1]["p_pred"])
+        eng.upload_lk(pkg.SMC_SET_FILT, outs[-1]["lk"])
+        w_cov = s.w_cov()
+        ts = time.perf_counter()
+        n_ss = 10
+        for j in range(n_ss):
+            cov_m = pkg.proposal_cov(eng, comm, s, w_cov)
+            eng.mh_step_device_rng(1.0, 1.0, pkg.mvn_transform(cov_m), 424242, j, 0)
+        eng.synchronize()
+        dt_ss = time.perf_counter() - ts
+        tm_ss = eng.timing_get()
+        steady = {"particle_mutation_steps_per_s_wall": n_ss * n_local / dt_ss,
+                  "solve_kernel_ms_per_sweep": tm_ss["solve"]["ms"] / n_ss,
+                  "sweep_ms_wall": 1e3 * dt_ss / n_ss, "sweeps": n_ss}
+        eng.timing_enable(False)
+
     pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)          # global count
     sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs)
     ess_iters = sum(o["stats"]["ess_iters"] for o in outs)
@@ -156,6 +178,15 @@ def main():
         ach_tflops = flop_per_launch / (solve_ms * 1e-3) / 1e12
         hbm_gbps = HBM_BYTES_PER_PARTICLE_SOLVE * n_local / (solve_ms * 1e-3) / 1e9
         ess_ms = timing["ess"]["ms"]
+        traffic = None
+        try:   # HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc passes (profiles/)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_fetch_write_summary.json")))
+            k = "void smc::mm_solve_kernel<false>"
+            # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes fetched
+            # (MI355X_MICROARCH.md, HBM section; confirmed here on mm_propose_kernel: 11.8 MiB reported for 24 MB read)
+            traffic = (2 * pmc["pmc_fetch"][k]["avg_counter_value"] + pmc["pmc_write"][k]["avg_counter_value"]) * 1024
+        except Exception:
+            pass
         result = {
             "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -170,10 +201,14 @@ def main():
             "mutation_sweeps": sweeps, "logZ": [o["logZ"] for o in outs],
             "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(),
             "kernel_ms": {k: v for k, v in timing.items()},
+            "steady_state": steady,
             "roofline": {"kernel": "mm_solve_kernel<false> (persistent RK45 solve, lane-level dynamic scheduling)",
                          "bound": "fp64-valu",
                          "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this "
+                                         "command (profiles/r01_b_pmc_fetch_write_summary.json), FETCH_SIZE doubled",
+                         "peak_measured_fp64_fma_tflops": 57.3,
                          "avg_launch_ms": solve_ms, "launches": sv["launches"], "mh_sweep_avg_ms": mh_ms,
                          "algorithmic_flop_per_launch": flop_per_launch,
                          "hbm": {"algorithmic_bytes_per_launch": HBM_BYTES_PER_PARTICLE_SOLVE * n_local,

@@ -13,3 +13,4 @@ from .binding import (SMC_SET_FILT, SMC_SET_PRED, SmcError, header_symbols, lib,
 from .comm import RcclComm, SingleComm, TorchDistComm  # noqa: F401
 from .driver import SMCSettings, ess_candidates, ess_search, mvn_transform, proposal_cov, resample, run_smc, sample_prior  # noqa: F401
 from .engine import HipEngine  # noqa: F401
+from . import methanation  # noqa: F401

@@ -75,6 +75,10 @@ SIGNATURES = {
     "smc_timing_enable": (cint, [c_ctx, cint]),
     "smc_timing_reset": (cint, [c_ctx]),
     "smc_timing_get": (cint, [c_ctx, cint, c_i64p, c_dp]),
+    "smc_meth_last_error": (ctypes.c_char_p, []),
+    "smc_meth_residual_host": (cint, [cint, c_dp, c_dp, c_dp, i64, c_dp]),
+    "smc_meth_rate_host": (cint, [cint, c_dp, c_dp, i64, c_dp]),
+    "smc_meth_loglike_host": (cint, [cint, c_dp, c_dp, c_dp, i64, cint, c_dp]),
 }
 
 _LIB = None

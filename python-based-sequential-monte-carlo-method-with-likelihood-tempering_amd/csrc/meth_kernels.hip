@@ -1,0 +1,146 @@
+// meth_kernels.hip -- kernels of the methanation rows that can be pinned today (K7): batched DAE
+// residual, rate law, and the Gaussian log-likelihood from outlet flows.  The implicit DAE time
+// integrator (K8) is not built yet.  Context-free C-ABI entry points operating on
+// host buffers: they exist so that these device functions are parity-tested through the ABI before the
+// integrator is built on top of them.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/smc_hip.h"
+#include "meth_model.h"
+
+namespace smc {
+namespace meth {
+
+// one wave per state vector, lane = axial node (51 of 64 lanes active): neighbouring nodes are
+// neighbouring lanes, field-major rows are read coalesced
+__global__ void __launch_bounds__(64) residual_kernel(const double *__restrict__ X, const double *__restrict__ dX,
+                                                      const double *__restrict__ params, int64_t n,
+                                                      double *__restrict__ res) {
+    const int64_t b = blockIdx.x;
+    if (b >= n) return;
+    __shared__ double sX[NSTATE], sD[NSTATE], sP[NPAR];
+    for (int k = threadIdx.x; k < NSTATE; k += 64) {
+        sX[k] = X[b * NSTATE + k];
+        sD[k] = dX[b * NSTATE + k];
+    }
+    if (threadIdx.x < NPAR) sP[threadIdx.x] = params[b * NPAR + threadIdx.x];
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i >= NX) return;
+    double out[7];
+    node_residual(i, (const double *)sX, (const double *)sD, sP, out);
+    for (int f = 0; f < 7; ++f) res[b * NSTATE + f * NX + i] = out[f];
+}
+
+__global__ void rate_kernel(const double *__restrict__ in, const double *__restrict__ kin, int64_t n,
+                            double *__restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double k[8];
+    for (int q = 0; q < 8; ++q) k[q] = kin[j * 8 + q];
+    out[j] = rCH4(in[j * 5], in[j * 5 + 1], in[j * 5 + 2], in[j * 5 + 3], in[j * 5 + 4], k);
+}
+
+// my_loglike (methanation_set_likelihood.py:280-300): per particle, 5 components x n_data flows
+__global__ void loglike_kernel(const double *__restrict__ y, const double *__restrict__ data,
+                               const double *__restrict__ sigma, int64_t n, int n_data, double *__restrict__ lk) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double s = sigma[j];
+    const double c = -(0.5 / (s * s)), l = n_data * log(s);
+    double total = 0.0;
+    for (int i = 0; i < 5; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k < n_data; ++k) {
+            const double d = y[(j * 5 + i) * n_data + k] - data[i * n_data + k];
+            acc += d * d;
+        }
+        total += c * acc - l;
+    }
+    lk[j] = total;
+}
+
+}  // namespace meth
+}  // namespace smc
+
+static thread_local std::string g_meth_err;
+#define MH(call)                                                                 \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            g_meth_err = std::string(#call) + ": " + hipGetErrorString(e_);      \
+            for (void *q : bufs) (void)hipFree(q);                               \
+            return 1;                                                            \
+        }                                                                        \
+    } while (0)
+
+#include <vector>
+
+extern "C" {
+
+const char *smc_meth_last_error(void) { return g_meth_err.c_str(); }
+
+int smc_meth_residual_host(int device, const double *X, const double *dX, const double *params, int64_t n,
+                           double *res) {
+    using namespace smc::meth;
+    std::vector<void *> bufs;
+    if (n <= 0) return 0;
+    MH(hipSetDevice(device));
+    double *dXs, *dDs, *dP, *dR;
+    const size_t sb = (size_t)n * NSTATE * sizeof(double);
+    MH(hipMalloc(&dXs, sb)); bufs.push_back(dXs);
+    MH(hipMalloc(&dDs, sb)); bufs.push_back(dDs);
+    MH(hipMalloc(&dP, (size_t)n * NPAR * sizeof(double))); bufs.push_back(dP);
+    MH(hipMalloc(&dR, sb)); bufs.push_back(dR);
+    MH(hipMemcpy(dXs, X, sb, hipMemcpyHostToDevice));
+    MH(hipMemcpy(dDs, dX, sb, hipMemcpyHostToDevice));
+    MH(hipMemcpy(dP, params, (size_t)n * NPAR * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(residual_kernel, dim3((unsigned)n), dim3(64), 0, 0, dXs, dDs, dP, n, dR);
+    MH(hipGetLastError());
+    MH(hipMemcpy(res, dR, sb, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+int smc_meth_rate_host(int device, const double *in, const double *kin, int64_t n, double *out) {
+    using namespace smc::meth;
+    std::vector<void *> bufs;
+    if (n <= 0) return 0;
+    MH(hipSetDevice(device));
+    double *dI, *dK, *dO;
+    MH(hipMalloc(&dI, (size_t)n * 5 * 8)); bufs.push_back(dI);
+    MH(hipMalloc(&dK, (size_t)n * 8 * 8)); bufs.push_back(dK);
+    MH(hipMalloc(&dO, (size_t)n * 8)); bufs.push_back(dO);
+    MH(hipMemcpy(dI, in, (size_t)n * 5 * 8, hipMemcpyHostToDevice));
+    MH(hipMemcpy(dK, kin, (size_t)n * 8 * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dI, dK, n, dO);
+    MH(hipGetLastError());
+    MH(hipMemcpy(out, dO, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+int smc_meth_loglike_host(int device, const double *y, const double *data, const double *sigma, int64_t n, int n_data,
+                          double *lk) {
+    using namespace smc::meth;
+    std::vector<void *> bufs;
+    if (n <= 0) return 0;
+    MH(hipSetDevice(device));
+    double *dY, *dD, *dS, *dL;
+    MH(hipMalloc(&dY, (size_t)n * 5 * n_data * 8)); bufs.push_back(dY);
+    MH(hipMalloc(&dD, (size_t)5 * n_data * 8)); bufs.push_back(dD);
+    MH(hipMalloc(&dS, (size_t)n * 8)); bufs.push_back(dS);
+    MH(hipMalloc(&dL, (size_t)n * 8)); bufs.push_back(dL);
+    MH(hipMemcpy(dY, y, (size_t)n * 5 * n_data * 8, hipMemcpyHostToDevice));
+    MH(hipMemcpy(dD, data, (size_t)5 * n_data * 8, hipMemcpyHostToDevice));
+    MH(hipMemcpy(dS, sigma, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dY, dD, dS, n, n_data, dL);
+    MH(hipGetLastError());
+    MH(hipMemcpy(lk, dL, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+}  // extern "C"
