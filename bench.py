@@ -104,7 +104,9 @@ def main():
     t, P_obs, S0 = load_mm_data()
     s = pkg.SMCSettings(n_particle=n_global)
 
-    eng = pkg.HipEngine(n_local, 3, device=local_rank, n_global=n_global)
+    # SMC_BENCH_DEVICE pins every rank to one device (rehearsing the multi-rank path on a one-GPU box)
+    dev = int(os.environ.get("SMC_BENCH_DEVICE", local_rank))
+    eng = pkg.HipEngine(n_local, 3, device=dev, n_global=n_global)
     eng.set_model_mm(t, P_obs, S0)
     eng.set_prior(s.priors)
     if world > 1:
