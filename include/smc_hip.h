@@ -161,6 +161,14 @@ int smc_comm_allgather_f64(smc_ctx *ctx, const double *in, int n, double *out /*
 int smc_comm_allgather_i64(smc_ctx *ctx, const int64_t *in, int n, int64_t *out /* world*n */);
 int smc_comm_barrier(smc_ctx *ctx);
 
+/* Loopback rehearsal of the multi-rank path on ONE device: `peers` are the `world` contexts of one process
+ * (peers[rank] == ctx), typically one host thread per rank.  smc_resample_phase3 then only packs (gathers own
+ * slots, stages remote ones, synchronises its stream); after a barrier between the threads every rank calls
+ * smc_resample_phase3_pull, which copies its incoming slots out of the peers' staging buffers (device-to-
+ * device) instead of the RCCL send/recv pairs.  Everything else (kernels, offsets, counts) is the RCCL path. */
+int smc_debug_set_local_peers(smc_ctx *ctx, smc_ctx **peers, int rank, int world);
+int smc_resample_phase3_pull(smc_ctx *ctx);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the kernels launched on the context's stream: smc_timing_reset clears the
  * accumulators; smc_timing_get returns, for kernel class `which`, launches and total milliseconds

@@ -546,7 +546,7 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
         HIPC(c, hipMalloc(&c->d_sendbuf, (size_t)remote * (d + 1) * sizeof(double)));
         c->sendbuf_cap = remote;
     }
-    if (W > 1 && !c->nccl_comm) return fail(c, "world > 1 but smc_comm_init has not been called");
+    if (W > 1 && !c->nccl_comm && c->peers.empty()) return fail(c, "world > 1 but smc_comm_init has not been called");
 
     // 1. gather: own slots straight into p_filt / lk1, remote slots into the send staging
     int64_t soff = 0;
@@ -571,6 +571,14 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
         if (lo < nl) launch_resample_stale(c, lo, nl, first_step);
     }
     HIPC(c, hipGetLastError());
+    c->plan_send_off = send_off;
+    c->plan_send_cnt = send_cnt;
+    c->plan_base.assign(out_base_all, out_base_all + W);
+    c->plan_cnt.assign(offspring_all, offspring_all + W);
+    if (W > 1 && !c->peers.empty()) {  // loopback rehearsal: the pull happens after a barrier between the ranks
+        HIPC(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
     // 3. exchange: per peer and component one send / one recv, received straight into the SoA rows
     if (W > 1) {
         ncclComm_t comm = (ncclComm_t)c->nccl_comm;
@@ -592,6 +600,41 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
         }
         NCCLC(c, ncclGroupEnd());
     }
+    return 0;
+}
+
+int smc_debug_set_local_peers(smc_ctx *c, smc_ctx **peers, int rank, int world) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (world < 1 || world > SMC_MAX_RANKS || rank < 0 || rank >= world || peers[rank] != c) return fail(c, "bad peer set");
+    if (c->n_global != c->n_local * world) return fail(c, "n_global must equal world * n_local");
+    c->peers.assign(peers, peers + world);
+    c->rank = rank;
+    c->world = world;
+    return 0;
+}
+
+int smc_resample_phase3_pull(smc_ctx *c) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (c->peers.empty()) return fail(c, "smc_debug_set_local_peers has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    const int W = c->world, R = c->rank, d = c->dim;
+    const int64_t nl = c->n_local;
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    for (int q = 0; q < W; ++q) {
+        if (q == R) continue;
+        smc_ctx *src = c->peers[q];
+        const int64_t lo = imax(c->plan_base[q], R * nl), hi = imin(c->plan_base[q] + c->plan_cnt[q], (R + 1) * nl);
+        if (hi <= lo) continue;
+        const int64_t off = lo - R * nl, cnt = hi - lo;
+        if (src->plan_send_cnt[R] != cnt) return fail(c, "loopback exchange: sender and receiver disagree on a count");
+        const double *blk = src->d_sendbuf + (size_t)src->plan_send_off[R] * (d + 1);
+        for (int k = 0; k < d; ++k)
+            HIPC(c, hipMemcpyAsync(F.theta + (size_t)k * F.stride + off, blk + (size_t)k * cnt, (size_t)cnt * sizeof(double),
+                                   hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(F.lk + off, blk + (size_t)d * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice,
+                               c->stream));
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -110,6 +110,9 @@ struct smc_ctx {
     // comm
     void *nccl_comm = nullptr;
     int rank = 0, world = 1;
+    // loopback rehearsal (smc_debug_set_local_peers): peer contexts on the same device, last exchange plan
+    std::vector<smc_ctx *> peers;
+    std::vector<int64_t> plan_send_off, plan_send_cnt, plan_base, plan_cnt;
 
     // timing
     int timing = 0;

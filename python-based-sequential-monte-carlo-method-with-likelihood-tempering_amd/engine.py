@@ -42,6 +42,7 @@ class HipEngine:
             raise SmcError(f"smc_create: {msg.decode() if msg else 'unknown error'}")
         self.ctx = ctx
         self.model = None
+        self._peer_barrier = None
 
     # ---- lifetime ------------------------------------------------------------------------------
     def close(self):
@@ -192,6 +193,17 @@ class HipEngine:
         assert b.shape == o.shape == (self.world,)
         self._ck(self.L.smc_resample_phase3(self.ctx, b.ctypes.data_as(B.c_i64p), o.ctypes.data_as(B.c_i64p),
                                             int(bool(first_step))), "smc_resample_phase3")
+        if self._peer_barrier is not None:      # loopback rehearsal: pack | barrier | pull | barrier
+            self._peer_barrier()
+            self._ck(self.L.smc_resample_phase3_pull(self.ctx), "smc_resample_phase3_pull")
+            self._peer_barrier()
+
+    def debug_set_local_peers(self, engines, rank, barrier):
+        """Loopback rehearsal of the multi-rank path on one device (see include/smc_hip.h)."""
+        arr = (B.c_ctx * len(engines))(*[e.ctx for e in engines])
+        self._ck(self.L.smc_debug_set_local_peers(self.ctx, arr, int(rank), len(engines)), "smc_debug_set_local_peers")
+        self.rank, self.world = int(rank), len(engines)
+        self._peer_barrier = barrier
 
     # ---- moments -------------------------------------------------------------------------------
     def moment_sums_local(self):
