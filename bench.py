@@ -182,7 +182,7 @@ def main():
         ess_ms = timing["ess"]["ms"]
         traffic = None
         try:   # HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc passes (profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_fetch_write_summary.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write_summary.json")))
             k = "void smc::mm_solve_kernel<false>"
             # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes fetched
             # (MI355X_MICROARCH.md, HBM section; confirmed here on mm_propose_kernel: 11.8 MiB reported for 24 MB read)
@@ -209,7 +209,7 @@ def main():
                          "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this "
-                                         "command (profiles/r01_b_pmc_fetch_write_summary.json), FETCH_SIZE doubled",
+                                         "command (profiles/r01_c_pmc_fetch_write_summary.json), FETCH_SIZE doubled",
                          "peak_measured_fp64_fma_tflops": 57.3,
                          "avg_launch_ms": solve_ms, "launches": sv["launches"], "mh_sweep_avg_ms": mh_ms,
                          "algorithmic_flop_per_launch": flop_per_launch,
