@@ -1,0 +1,361 @@
+/*
+ * oracle/meth_dae_oracle.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU implementation of the time integration of the methanation DAE F(t, X, X'; p) = 0
+ * (reaction(), SMC_methanation/methanation_set_likelihood.py:69-139) from the driver's initial guess
+ * (SMC_methanation_main.py:47-58) to t = 75 s, and of my_model's outlet mapping (:204-208).
+ *
+ * PARITY UNPINNED.  The reference integrates with Assimulo's IDA (SUNDIALS; variable-order BDF, :167-198,
+ * rtol = atol = 1e-6, suppress_alg, IDA_YA_YDP_INIT).  Assimulo/SUNDIALS are absent from this image, their
+ * source is not under /root/reference, the reference's inlet table is missing and no output of my_model for
+ * known inputs exists - IDA's step/order heuristics cannot be restated or checked.  What is implemented here is
+ * an integrator of the SAME CLASS solving the SAME equations to the SAME tolerances:
+ *     variable-order (1-5) BDF/NDF in the quasi-constant-step form of SciPy's BDF (scipy/integrate/_ivp/
+ *     bdf.py, Shampine & Reichelt), adapted to the fully implicit residual: the corrector solves
+ *     G(d) = F(t_new, y_pred + d, (psi + d)/c) = 0 by modified Newton with the iteration matrix
+ *     dF/dy + (1/c) dF/dy', evaluated at the predictor at every step; error test on the differential
+ *     variables only (suppress_alg); first step of order 1 from y'(0) = 0 (the reference's yd0).
+ * It is checked by (tests/test_methanation_dae.py): agreement with SciPy's own BDF on an ODE written as
+ * F = y' - f; tolerance refinement (1e-6 vs 1e-9 runs); vanishing residual of the steady state it reaches.
+ * The HIP kernel implements the same algorithm and is compared with this file.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NX 51
+#define NS 357
+#define KB 13             /* half bandwidth in node-major ordering */
+#define LDAB (3 * KB + 1) /* banded storage with room for pivoting fill-in */
+#define MAX_ORDER 5
+#define NEWTON_MAXITER 4
+
+void meth_reaction(const double *X, const double *dX, const double *params, double *res);
+void meth_flows(const double *y, double P_total, double S, double P_stp, double *F);
+
+typedef struct {
+    int64_t steps, rejects, nlu, nres, newton_fail;
+    int32_t status; /* 0 ok, -1 step underflow / too many steps */
+    int32_t order_hist[6];
+} dae_stats;
+
+typedef void (*resid_fn)(const double *y, const double *yd, const double *p, double *res, void *user);
+
+static void meth_resid(const double *y, const double *yd, const double *p, double *res, void *user) {
+    (void)user;
+    meth_reaction(y, yd, p, res);
+}
+
+/* node-major index k = 7*i + f  <->  field-major f*51 + i */
+static inline int fm_of_nm(int k) { return (k % 7) * NX + k / 7; }
+
+/* banded LU with partial pivoting (LAPACK dgbtf2 layout: AB(kl+ku+1+i-j, j) = A(i,j), kl = ku = KB) */
+static int band_factor(double *ab, int *piv, int n) {
+    const int kl = KB, ku = KB, kv = kl + ku;
+    for (int j = 0; j < n; ++j) {
+        int km = (kl < n - 1 - j) ? kl : n - 1 - j;
+        int jp = 0;
+        double mx = fabs(ab[kv + j * LDAB]);
+        for (int i = 1; i <= km; ++i) {
+            double v = fabs(ab[kv + i + j * LDAB]);
+            if (v > mx) { mx = v; jp = i; }
+        }
+        piv[j] = j + jp;
+        if (mx == 0.0) return -1;
+        int ju = (j + ku + jp < n - 1) ? j + ku + jp : n - 1; /* last column touched */
+        if (jp != 0)
+            for (int c = j; c <= ju; ++c) {
+                double t = ab[kv + jp + j - c + c * LDAB];
+                ab[kv + jp + j - c + c * LDAB] = ab[kv + j - c + c * LDAB];
+                ab[kv + j - c + c * LDAB] = t;
+            }
+        double r = 1.0 / ab[kv + j * LDAB];
+        for (int i = 1; i <= km; ++i) ab[kv + i + j * LDAB] *= r;
+        for (int c = j + 1; c <= ju; ++c) {
+            double t = ab[kv + j - c + c * LDAB];
+            if (t != 0.0)
+                for (int i = 1; i <= km; ++i) ab[kv + i + j - c + c * LDAB] -= ab[kv + i + j * LDAB] * t;
+        }
+    }
+    return 0;
+}
+static void band_solve(const double *ab, const int *piv, int n, double *b) {
+    const int kl = KB, ku = KB, kv = kl + ku;
+    for (int j = 0; j < n; ++j) {
+        int km = (kl < n - 1 - j) ? kl : n - 1 - j;
+        int l = piv[j];
+        if (l != j) { double t = b[l]; b[l] = b[j]; b[j] = t; }
+        for (int i = 1; i <= km; ++i) b[j + i] -= ab[kv + i + j * LDAB] * b[j];
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        b[j] /= ab[kv + j * LDAB];
+        int lo = (j - kv > 0) ? j - kv : 0;
+        for (int i = lo; i < j; ++i) b[i] -= ab[kv + i - j + j * LDAB] * b[j];
+    }
+}
+
+/* iteration matrix dG/dd = dF/dy + (1/c) dF/dy' at (y, yd) by coloured finite differences of the residual:
+ * 21 evaluations (7 fields x 3 node classes), columns perturbed together never share a row. */
+static void iteration_matrix(resid_fn F, void *user, const double *y, const double *yd, const double *p, double c,
+                             double *ab, int n_fields, int64_t *nres) {
+    static const double SQRT_EPS = 1.4901161193847656e-08;
+    double f0[NS], f1[NS], yp[NS], ydp[NS], hcol[NS];
+    memset(ab, 0, sizeof(double) * LDAB * NS);
+    F(y, yd, p, f0, user);
+    (*nres)++;
+    const int kv = 2 * KB;
+    for (int f = 0; f < n_fields; ++f)
+        for (int cls = 0; cls < 3; ++cls) {
+            memcpy(yp, y, sizeof yp);
+            memcpy(ydp, yd, sizeof ydp);
+            for (int i = cls; i < NX; i += 3) {
+                int col = f * NX + i;
+                double h = SQRT_EPS * fmax(fabs(y[col]), 1e-3);
+                double tmp = y[col] + h;
+                h = tmp - y[col];
+                hcol[col] = h;
+                yp[col] = tmp;
+                ydp[col] = yd[col] + h / c;
+            }
+            F(yp, ydp, p, f1, user);
+            (*nres)++;
+            for (int i = cls; i < NX; i += 3) {
+                int col = f * NX + i, jc = 7 * i + f;
+                for (int ii = i - 1; ii <= i + 1; ++ii) {
+                    if (ii < 0 || ii >= NX) continue;
+                    for (int g = 0; g < 7; ++g) {
+                        int row = g * NX + ii, ir = 7 * ii + g;
+                        ab[kv + ir - jc + jc * LDAB] = (f1[row] - f0[row]) / hcol[col];
+                    }
+                }
+            }
+        }
+}
+
+static double rms_masked(const double *v, const double *scale, const unsigned char *mask, int n) {
+    double s = 0.0;
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (!mask || mask[i]) {
+            double q = v[i] / scale[i];
+            s += q * q;
+            m++;
+        }
+    return sqrt(s / (m ? m : 1));
+}
+
+/* scipy bdf.py: compute_R / change_D */
+static void change_D(double D[][NS], int order, double factor, int n) {
+    double R[6][6], U[6][6], RU[6][6], tmp[6];
+    for (int pass = 0; pass < 2; ++pass) {
+        double (*M)[6] = pass ? U : R;
+        double fac = pass ? 1.0 : factor;
+        for (int j = 0; j <= order; ++j) M[0][j] = 1.0;
+        for (int i = 1; i <= order; ++i) {
+            M[i][0] = 0.0;
+            for (int j = 1; j <= order; ++j) M[i][j] = M[i - 1][j] * ((i - 1 - fac * j) / i);
+        }
+        /* column 0 of cumprod: M[0][0] = 1, M[i][0] = 0 */
+    }
+    for (int i = 0; i <= order; ++i)
+        for (int j = 0; j <= order; ++j) {
+            double s = 0.0;
+            for (int k = 0; k <= order; ++k) s += R[i][k] * U[k][j];
+            RU[i][j] = s;
+        }
+    for (int x = 0; x < n; ++x) {
+        for (int j = 0; j <= order; ++j) {
+            double s = 0.0;
+            for (int i = 0; i <= order; ++i) s += RU[i][j] * D[i][x];
+            tmp[j] = s;
+        }
+        for (int j = 0; j <= order; ++j) D[j][x] = tmp[j];
+    }
+}
+
+/*
+ * Integrate F(y, y'; p) = 0 from (0, y0) with y'(0) = 0 to tf.  diff_mask[i] = 1 for differential variables
+ * (error test), n = number of active unknowns (<= NS; the generic entry is used by the unit test on an ODE).
+ */
+int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p, int n, int n_fields,
+                      const unsigned char *diff_mask, double tf, double rtol, double atol, double h0, double *y_out,
+                      dae_stats *st) {
+    static const double kappa[6] = {0, -0.1850, -1.0 / 9, -0.0823, -0.0415, 0};
+    double gamma[6], alpha[6], error_const[7];
+    gamma[0] = 0.0;
+    for (int k = 1; k <= MAX_ORDER; ++k) gamma[k] = gamma[k - 1] + 1.0 / k;
+    for (int k = 0; k <= MAX_ORDER; ++k) alpha[k] = (1 - kappa[k]) * gamma[k];
+    for (int k = 0; k <= MAX_ORDER; ++k) error_const[k] = kappa[k] * gamma[k] + 1.0 / (k + 1);
+    error_const[MAX_ORDER + 1] = 1.0 / (MAX_ORDER + 2);
+
+    double(*D)[NS] = calloc(MAX_ORDER + 3, sizeof *D);
+    double *ab = malloc(sizeof(double) * LDAB * NS);
+    int piv[NS];
+    double y_pred[NS], psi[NS], scale[NS], y[NS], d[NS], r[NS], dy[NS], ydot[NS], tmpv[NS];
+    memset(st, 0, sizeof *st);
+    memcpy(D[0], y0, sizeof(double) * NS);
+    const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+    double t = 0.0, h_abs = h0;
+    int order = 1, n_equal = 0, rc = 0;
+    const int64_t max_steps = 200000;
+
+    while (t < tf && rc == 0) {
+        int accepted = 0, n_iter = 0;
+        double error_norm = 0.0, safety = 0.9, t_new = t;
+        while (!accepted) {
+            if (h_abs < 1e-14 * fmax(1.0, t) || st->steps + st->rejects + st->newton_fail > max_steps) { rc = -1; break; }
+            t_new = t + h_abs;
+            if (t_new - tf > 0) {
+                t_new = tf;
+                change_D(D, order, fabs(t_new - t) / h_abs, NS);
+                n_equal = 0;
+            }
+            const double h = t_new - t;
+            h_abs = fabs(h);
+            for (int i = 0; i < NS; ++i) {
+                double s = 0.0, q = 0.0;
+                for (int k = 0; k <= order; ++k) s += D[k][i];
+                for (int k = 1; k <= order; ++k) q += D[k][i] * gamma[k];
+                y_pred[i] = s;
+                psi[i] = q / alpha[order];
+                scale[i] = atol + rtol * fabs(s);
+            }
+            const double c = h / alpha[order];
+            /* iteration matrix at the predictor, every step */
+            for (int i = 0; i < NS; ++i) ydot[i] = psi[i] / c;
+            iteration_matrix(F, user, y_pred, ydot, p, c, ab, n_fields, &st->nres);
+            st->nlu++;
+            int converged = 0;
+            if (band_factor(ab, piv, NS) == 0) {
+                memcpy(y, y_pred, sizeof y);
+                memset(d, 0, sizeof d);
+                double dy_norm_old = -1.0;
+                for (int k = 0; k < NEWTON_MAXITER; ++k) {
+                    for (int i = 0; i < NS; ++i) ydot[i] = (psi[i] + d[i]) / c;
+                    F(y, ydot, p, r, user);
+                    st->nres++;
+                    n_iter = k + 1;
+                    int finite = 1;
+                    for (int i = 0; i < n; ++i)
+                        if (!isfinite(r[i])) finite = 0;
+                    if (!finite) break;
+                    for (int k2 = 0; k2 < NS; ++k2) {
+                        int fm = fm_of_nm(k2);
+                        tmpv[k2] = (fm < n) ? -r[fm] : 0.0;
+                    }
+                    band_solve(ab, piv, NS, tmpv);
+                    for (int k2 = 0; k2 < NS; ++k2) dy[fm_of_nm(k2)] = tmpv[k2];
+                    const double dy_norm = rms_masked(dy, scale, NULL, n);
+                    double rate = -1.0;
+                    if (dy_norm_old >= 0) rate = dy_norm / dy_norm_old;
+                    if (rate >= 0 && (rate >= 1 || pow(rate, NEWTON_MAXITER - k) / (1 - rate) * dy_norm > newton_tol)) break;
+                    for (int i = 0; i < n; ++i) { y[i] += dy[i]; d[i] += dy[i]; }
+                    if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = 1; break; }
+                    dy_norm_old = dy_norm;
+                }
+            }
+            if (!converged) {
+                st->newton_fail++;
+                h_abs *= 0.5;
+                change_D(D, order, 0.5, NS);
+                n_equal = 0;
+                continue;
+            }
+            safety = 0.9 * (2 * NEWTON_MAXITER + 1) / (2.0 * NEWTON_MAXITER + n_iter);
+            for (int i = 0; i < NS; ++i) { scale[i] = atol + rtol * fabs(y[i]); tmpv[i] = error_const[order] * d[i]; }
+            error_norm = rms_masked(tmpv, scale, diff_mask, n);
+            if (error_norm > 1) {
+                st->rejects++;
+                double factor = fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1)));
+                h_abs *= factor;
+                change_D(D, order, factor, NS);
+                n_equal = 0;
+            } else {
+                accepted = 1;
+            }
+        }
+        if (rc) break;
+        n_equal++;
+        t = t_new;
+        st->steps++;
+        st->order_hist[order]++;
+        for (int i = 0; i < NS; ++i) {
+            D[order + 2][i] = d[i] - D[order + 1][i];
+            D[order + 1][i] = d[i];
+            for (int k = order; k >= 0; --k) D[k][i] += D[k + 1][i];
+        }
+        if (n_equal < order + 1) continue;
+        double em = INFINITY, ep = INFINITY;
+        if (order > 1) {
+            for (int i = 0; i < NS; ++i) tmpv[i] = error_const[order - 1] * D[order][i];
+            em = rms_masked(tmpv, scale, diff_mask, n);
+        }
+        if (order < MAX_ORDER) {
+            for (int i = 0; i < NS; ++i) tmpv[i] = error_const[order + 1] * D[order + 2][i];
+            ep = rms_masked(tmpv, scale, diff_mask, n);
+        }
+        double fm = pow(em, -1.0 / order), f0 = pow(error_norm, -1.0 / (order + 1)), fp = pow(ep, -1.0 / (order + 2));
+        int delta = 0; /* np.argmax: first maximum */
+        double best = fm;
+        delta = -1;
+        if (f0 > best) { best = f0; delta = 0; }
+        if (fp > best) { best = fp; delta = 1; }
+        order += delta;
+        double factor = fmin(10.0, safety * best);
+        h_abs *= factor;
+        change_D(D, order, factor, NS);
+        n_equal = 0;
+    }
+    memcpy(y_out, D[0], sizeof(double) * NS);
+    st->status = rc;
+    free(D);
+    free(ab);
+    return rc;
+}
+
+/* my_model (methanation_set_likelihood.py:144-277) for ONE experiment: integrate, map the outlet node to the
+ * five standard-state flows (:204-208); on failure the reference's sentinel -10000 (:244-249). */
+int meth_dae_solve(const double *y0, const double *p, double tf, double rtol, double atol, double h0, double *y_out,
+                   dae_stats *st) {
+    unsigned char mask[NS];
+    for (int i = 0; i < NS; ++i) mask[i] = (i < 6 * NX);
+    return dae_bdf_integrate(meth_resid, NULL, y0, p, NS, 7, mask, tf, rtol, atol, h0, y_out, st);
+}
+
+void meth_model_one(const double *y0, const double *p, double S, double P_stp, double *flows, double *y_final,
+                    dae_stats *st) {
+    double y[NS];
+    int rc = meth_dae_solve(y0, p, 75.0, 1e-6, 1e-6, 1e-5, y, st);
+    if (rc != 0) {
+        for (int f = 0; f < 5; ++f) flows[f] = -10000.0;
+    } else {
+        double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * 8.3144589 * p[5]; /* :165 */
+        meth_flows(y, P_total, S, P_stp, flows);
+    }
+    if (y_final) memcpy(y_final, y, sizeof y);
+}
+
+/* ---- generic ODE test problem: F = y' - f(y), Robertson-like stiff kinetics on 3 unknowns ----
+ * (fields 0..2 at node 0 carry the three unknowns; everything else is padded with identity rows) */
+static void ode_resid(const double *y, const double *yd, const double *p, double *res, void *user) {
+    (void)user;
+    for (int i = 0; i < NS; ++i) res[i] = y[i]; /* padding unknowns: y_i = 0 */
+    const double a = y[0], b = y[NX], c = y[2 * NX];
+    res[0] = yd[0] - (-p[0] * a + p[1] * b * c);
+    res[NX] = yd[NX] - (p[0] * a - p[1] * b * c - p[2] * b * b);
+    res[2 * NX] = yd[2 * NX] - (p[2] * b * b);
+}
+int dae_bdf_test_ode(const double *y0_3, const double *k3, double tf, double rtol, double atol, double h0, double *y3,
+                     dae_stats *st) {
+    double y0[NS], y[NS];
+    unsigned char mask[NS];
+    memset(y0, 0, sizeof y0);
+    memset(mask, 0, sizeof mask);
+    y0[0] = y0_3[0]; y0[NX] = y0_3[1]; y0[2 * NX] = y0_3[2];
+    mask[0] = mask[NX] = mask[2 * NX] = 1;
+    int rc = dae_bdf_integrate(ode_resid, NULL, y0, k3, NS, 7, mask, tf, rtol, atol, h0, y, st);
+    y3[0] = y[0]; y3[1] = y[NX]; y3[2] = y[2 * NX];
+    return rc;
+}

@@ -157,3 +157,68 @@ def cal_prior(theta):
     hi = np.array([high_limit[i] for i in est_position])
     p = scipy.stats.uniform.pdf(theta, lo, hi - lo)
     return np.prod(p.T, axis=0)
+
+
+# ---- DAE time integration (parity UNPINNED; see oracle/meth_dae_oracle.c) ----------------------------------
+class DaeStats(ctypes.Structure):
+    _fields_ = [("steps", ctypes.c_int64), ("rejects", ctypes.c_int64), ("nlu", ctypes.c_int64), ("nres", ctypes.c_int64),
+                ("newton_fail", ctypes.c_int64), ("status", ctypes.c_int32), ("order_hist", ctypes.c_int32 * 6)]
+
+    def asdict(self):
+        return {"steps": self.steps, "rejects": self.rejects, "nlu": self.nlu, "nres": self.nres,
+                "newton_fail": self.newton_fail, "status": self.status, "order_hist": list(self.order_hist)}
+
+
+def _dae_lib():
+    L = lib()
+    L.meth_dae_solve.restype = ctypes.c_int
+    L.meth_dae_solve.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp,
+                                 ctypes.POINTER(DaeStats)]
+    L.meth_model_one.restype = None
+    L.meth_model_one.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_double, _dp, _dp, ctypes.POINTER(DaeStats)]
+    L.dae_bdf_test_ode.restype = ctypes.c_int
+    L.dae_bdf_test_ode.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp,
+                                   ctypes.POINTER(DaeStats)]
+    return L
+
+
+def dae_solve(y0, p, tf=75.0, rtol=1e-6, atol=1e-6, h0=1e-5):
+    y0 = np.ascontiguousarray(y0, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.empty(7 * NX)
+    st = DaeStats()
+    rc = _dae_lib().meth_dae_solve(_p(y0), _p(p), tf, rtol, atol, h0, _p(out), ctypes.byref(st))
+    return out, rc, st.asdict()
+
+
+def p0_tuple(cond, i, pr):
+    """The p0 tuple of my_model (methanation_set_likelihood.py:164)."""
+    return np.array([cond["Ca_in"][i], cond["Cb_in"][i], cond["Cc_in"][i], cond["Cd_in"][i], cond["Ce_in"][i],
+                     cond["T_in"][i], cond["T_jacket"][i], cond["u_in"][i], cond["void"][i],
+                     cond["reactorlength"][i] / (NX - 1), *np.asarray(pr, dtype=np.float64)[:8]], dtype=np.float64)
+
+
+def my_model(params, cond, guess):
+    """Flows (5, n_data) and outlet states for one parameter vector (methanation_set_likelihood.py:144-277)."""
+    n_data = cond["n_data"]
+    flows = np.empty((5, n_data))
+    states = np.empty((n_data, 7 * NX))
+    stats = []
+    L = _dae_lib()
+    for i in range(n_data):
+        p = p0_tuple(cond, i, params)
+        f = np.empty(5)
+        st = DaeStats()
+        L.meth_model_one(_p(np.ascontiguousarray(guess[i])), _p(p), S_AREA, P_STP, _p(f), _p(states[i]), ctypes.byref(st))
+        flows[:, i] = f
+        stats.append(st.asdict())
+    return flows, states, stats
+
+
+def bdf_test_ode(y0, k, tf, rtol, atol, h0=1e-5):
+    y0 = np.ascontiguousarray(y0, dtype=np.float64)
+    k = np.ascontiguousarray(k, dtype=np.float64)
+    out = np.empty(3)
+    st = DaeStats()
+    rc = _dae_lib().dae_bdf_test_ode(_p(y0), _p(k), tf, rtol, atol, h0, _p(out), ctypes.byref(st))
+    return out, rc, st.asdict()

@@ -1,0 +1,64 @@
+"""CPU tests of the oracle's DAE time integration (oracle/meth_dae_oracle.c).  PARITY UNPINNED against the
+reference's IDA (absent); what is checked: the integrator core against SciPy's BDF on an ODE, tolerance
+refinement, the steady state it reaches, plausibility of my_model's outputs."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def M():
+    import __graft_entry__ as g
+    g.load_oracle()
+    from oracle import methanation
+    return methanation
+
+
+@pytest.fixture(scope="module")
+def setup(M):
+    cond = M.load_conditions(os.path.join(GOLD, "methanation_information.csv"))
+    return cond, M.initial_guess(cond)
+
+
+def test_bdf_core_against_scipy_on_stiff_ode(M):
+    from scipy.integrate import solve_ivp
+    k = [0.04, 1e4, 3e7]   # Robertson
+    f = lambda t, y: [-k[0] * y[0] + k[1] * y[1] * y[2], k[0] * y[0] - k[1] * y[1] * y[2] - k[2] * y[1] ** 2, k[2] * y[1] ** 2]
+    ref = solve_ivp(f, (0, 40), [1, 0, 0], method="BDF", rtol=1e-11, atol=1e-14).y[:, -1]
+    y6, rc6, st6 = M.bdf_test_ode([1, 0, 0], k, 40.0, 1e-6, 1e-10)
+    y9, rc9, st9 = M.bdf_test_ode([1, 0, 0], k, 40.0, 1e-9, 1e-13)
+    assert rc6 == 0 and rc9 == 0
+    assert np.max(np.abs(y6 - ref) / np.abs(ref)) < 2e-5
+    assert np.max(np.abs(y9 - ref) / np.abs(ref)) < 1e-7
+    assert st9["steps"] > st6["steps"] and max(np.nonzero(st6["order_hist"])[0]) >= 3
+
+
+@pytest.mark.parametrize("i", [0, 7, 19, 29])
+def test_tolerance_refinement_and_steady_state(M, setup, i):
+    cond, guess = setup
+    p = M.p0_tuple(cond, i, M.BASEPARAMS)
+    y, rc, st = M.dae_solve(guess[i], p)
+    assert rc == 0 and st["newton_fail"] == 0 and 150 < st["steps"] < 1000
+    yt, rc2, st2 = M.dae_solve(guess[i], p, rtol=1e-9, atol=1e-9)
+    outlet = [50, 101, 152, 203, 254, 305, 356]
+    assert rc2 == 0 and np.max(np.abs(yt - y)[outlet] / np.abs(yt[outlet])) < 5e-6
+    # t = 75 s is close to the steady state: integrating on to t = 2000 changes the outlet little and the
+    # residual with X' = 0 vanishes there
+    ys, rc3, _ = M.dae_solve(guess[i], p, tf=2000.0)
+    assert rc3 == 0 and np.max(np.abs(ys - y)[outlet] / np.abs(ys[outlet])) < 5e-3
+    r = M.reaction(ys, np.zeros(357), p)
+    assert np.abs(r[1:50]).max() < 1e-3 * np.abs(M.reaction(guess[i], np.zeros(357), p)).max()
+
+
+def test_my_model_outputs(M, setup):
+    cond, guess = setup
+    flows, states, stats = M.my_model(M.BASEPARAMS, cond, guess)
+    assert flows.shape == (5, 30) and np.all(flows > 0) and np.all(np.isfinite(flows))
+    # carbon balance at the outlet: CO2 + CH4 flow equals the CO2 fed (standard-state sccm, +-1 %)
+    info = np.loadtxt(os.path.join(GOLD, "methanation_information.csv"), delimiter=",", skiprows=1)[:30]
+    assert np.allclose(flows[1] + flows[2], info[:, 11], rtol=2e-2)
+    assert np.allclose(flows[4], info[:, 15], rtol=2e-2)          # argon is inert
+    assert all(s["status"] == 0 for s in stats)
