@@ -202,6 +202,17 @@ int smc_meth_rate_host(int device, const double *in, const double *kin, int64_t 
 int smc_meth_loglike_host(int device, const double *y, const double *data, const double *sigma, int64_t n, int n_data,
                           double *lk);
 
+/* The body of my_model (:161-208) for n_solves independent (particle, experiment) pairs: integrate
+ * F(t,X,X';p0) = 0 from X(0) = y0 (the driver's guess, SMC_methanation_main.py:47-58), X'(0) = 0 to tf with a
+ * variable-order BDF (rtol/atol as Assimulo's IDA defaults 1e-6) and map the outlet node to the five
+ * standard-state flows (:204-208).  PARITY UNPINNED against IDA (see csrc/meth_dae.h).  A failed solve
+ * (status != 0) returns the reference's sentinel flows -10000 (:244-249).
+ * p0_all: n_solves x 18, y0_all: n_solves x 357, flows: n_solves x 5, y_final (optional): n_solves x 357,
+ * status: n_solves, stats (optional): sums of steps, rejected steps, Newton failures, Newton iterations. */
+int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, int64_t n_solves, double tf, double rtol,
+                      double atol, double h0, double S, double P_stp, double *flows, double *y_final, int32_t *status,
+                      int64_t *stats, double *kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,8 @@ SIGNATURES = {
     "smc_meth_residual_host": (cint, [cint, c_dp, c_dp, c_dp, i64, c_dp]),
     "smc_meth_rate_host": (cint, [cint, c_dp, c_dp, i64, c_dp]),
     "smc_meth_loglike_host": (cint, [cint, c_dp, c_dp, c_dp, i64, cint, c_dp]),
+    "smc_meth_dae_host": (cint, [cint, c_dp, c_dp, i64, f64, f64, f64, f64, f64, f64, c_dp, c_dp,
+                                 ctypes.POINTER(ctypes.c_int32), c_i64p, c_dp]),
 }
 
 _LIB = None

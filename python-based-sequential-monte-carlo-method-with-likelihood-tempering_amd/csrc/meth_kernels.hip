@@ -1,13 +1,13 @@
-// meth_kernels.hip -- kernels of the methanation rows that can be pinned today (K7): batched DAE
-// residual, rate law, and the Gaussian log-likelihood from outlet flows.  The implicit DAE time
-// integrator (K8) is not built yet.  Context-free C-ABI entry points operating on
-// host buffers: they exist so that these device functions are parity-tested through the ABI before the
-// integrator is built on top of them.
+// meth_kernels.hip -- kernels of the methanation rows: K7 (batched DAE residual, rate law, Gaussian
+// log-likelihood from outlet flows; pinned against the reference's own functions) and K8 (the DAE time
+// integration of my_model, meth_dae.h; parity unpinned - no IDA to compare with).  Context-free C-ABI entry
+// points operating on host buffers.
 #include <hip/hip_runtime.h>
 
 #include <string>
 
 #include "../../include/smc_hip.h"
+#include "meth_dae.h"
 #include "meth_model.h"
 
 namespace smc {
@@ -60,6 +60,41 @@ __global__ void loglike_kernel(const double *__restrict__ y, const double *__res
         total += c * acc - l;
     }
     lk[j] = total;
+}
+
+// K8: one thread per (particle, experiment) solve; the per-solve workspace is interleaved across the
+// `nslots` threads of the launch (element idx of slot s at ws[idx*nslots + s]) so that the 64 lanes of a wave,
+// which execute the same statement on 64 independent solves, touch 64 consecutive doubles.
+__global__ void __launch_bounds__(64)
+dae_kernel(double *__restrict__ wsbuf, int64_t nslots, const double *__restrict__ p0_all,
+           const double *__restrict__ y0_all, int64_t n_solves, double tf, double rtol, double atol, double h0,
+           int max_attempts, double S, double P_stp, double *__restrict__ flows, double *__restrict__ y_final,
+           int *__restrict__ status, unsigned long long *__restrict__ counters) {
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    const Ws ws{wsbuf + slot, nslots};
+    for (int64_t sidx = slot; sidx < n_solves; sidx += nslots) {
+        double p[18];
+        for (int q = 0; q < 18; ++q) p[q] = p0_all[sidx * 18 + q];
+        for (int x = 0; x < kNS; ++x) ws(OFF_D + x) = y0_all[sidx * kNS + x];
+        for (int x = kNS; x < 8 * kNS; ++x) ws(OFF_D + x) = 0.0;
+        DaeStats st;
+        dae_integrate(ws, p, tf, rtol, atol, h0, max_attempts, st);
+        double F[5];
+        if (st.status == 0) {
+            outlet_flows(ws, p, S, P_stp, F);
+        } else {
+            for (int f = 0; f < 5; ++f) F[f] = -10000.0;  // the reference's failure sentinel (:244-249)
+        }
+        for (int f = 0; f < 5; ++f) flows[sidx * 5 + f] = F[f];
+        if (y_final)
+            for (int x = 0; x < kNS; ++x) y_final[sidx * kNS + x] = ws(OFF_D + x);
+        status[sidx] = st.status;
+        atomicAdd(&counters[0], (unsigned long long)st.steps);
+        atomicAdd(&counters[1], (unsigned long long)st.rejects);
+        atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
+        atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
+    }
 }
 
 }  // namespace meth
@@ -139,6 +174,57 @@ int smc_meth_loglike_host(int device, const double *y, const double *data, const
     hipLaunchKernelGGL(loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dY, dD, dS, n, n_data, dL);
     MH(hipGetLastError());
     MH(hipMemcpy(lk, dL, (size_t)n * 8, hipMemcpyDeviceToHost));
+    for (void *q : bufs) (void)hipFree(q);
+    return 0;
+}
+
+int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, int64_t n_solves, double tf, double rtol,
+                      double atol, double h0, double S, double P_stp, double *flows, double *y_final, int32_t *status,
+                      int64_t *stats, double *kernel_ms) {
+    using namespace smc::meth;
+    std::vector<void *> bufs;
+    if (n_solves <= 0) return 0;
+    MH(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MH(hipGetDeviceProperties(&prop, device));
+    int64_t nslots = ((n_solves + 63) / 64) * 64;
+    const int64_t max_slots = (int64_t)prop.multiProcessorCount * 256;   // 4 waves per CU
+    if (nslots > max_slots) nslots = max_slots;
+    double *dws, *dp, *dy0, *dfl, *dyf = nullptr;
+    int *dst;
+    unsigned long long *dcnt;
+    MH(hipMalloc(&dws, (size_t)nslots * kWsDoubles * sizeof(double))); bufs.push_back(dws);
+    MH(hipMalloc(&dp, (size_t)n_solves * 18 * 8)); bufs.push_back(dp);
+    MH(hipMalloc(&dy0, (size_t)n_solves * kNS * 8)); bufs.push_back(dy0);
+    MH(hipMalloc(&dfl, (size_t)n_solves * 5 * 8)); bufs.push_back(dfl);
+    MH(hipMalloc(&dst, (size_t)n_solves * sizeof(int))); bufs.push_back(dst);
+    MH(hipMalloc(&dcnt, 4 * sizeof(unsigned long long))); bufs.push_back(dcnt);
+    if (y_final) { MH(hipMalloc(&dyf, (size_t)n_solves * kNS * 8)); bufs.push_back(dyf); }
+    MH(hipMemcpy(dp, p0_all, (size_t)n_solves * 18 * 8, hipMemcpyHostToDevice));
+    MH(hipMemcpy(dy0, y0_all, (size_t)n_solves * kNS * 8, hipMemcpyHostToDevice));
+    MH(hipMemset(dcnt, 0, 4 * sizeof(unsigned long long)));
+    hipEvent_t e0, e1;
+    MH(hipEventCreate(&e0));
+    MH(hipEventCreate(&e1));
+    MH(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(dae_kernel, dim3((unsigned)(nslots / 64)), dim3(64), 0, 0, dws, nslots, dp, dy0, n_solves, tf, rtol,
+                       atol, h0, 20000, S, P_stp, dfl, dyf, dst, dcnt);
+    MH(hipGetLastError());
+    MH(hipEventRecord(e1, 0));
+    MH(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MH(hipEventElapsedTime(&ms, e0, e1));
+    if (kernel_ms) *kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    MH(hipMemcpy(flows, dfl, (size_t)n_solves * 5 * 8, hipMemcpyDeviceToHost));
+    MH(hipMemcpy(status, dst, (size_t)n_solves * sizeof(int), hipMemcpyDeviceToHost));
+    if (y_final) MH(hipMemcpy(y_final, dyf, (size_t)n_solves * kNS * 8, hipMemcpyDeviceToHost));
+    if (stats) {
+        unsigned long long h[4];
+        MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
+        for (int q = 0; q < 4; ++q) stats[q] = (int64_t)h[q];
+    }
     for (void *q : bufs) (void)hipFree(q);
     return 0;
 }

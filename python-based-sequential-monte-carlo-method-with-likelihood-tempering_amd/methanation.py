@@ -54,3 +54,27 @@ def my_loglike(y, data, sigma, n_data, device=0):
     _ck(lib().smc_meth_loglike_host(device, _dp(y), _dp(data), _dp(sigma), y.shape[0], int(n_data), _dp(lk)),
         "smc_meth_loglike_host")
     return lk[0] if single else lk
+
+
+S_AREA = np.pi * (0.01 / 2) ** 2          # methanation_set_conditon.py:80-81
+P_STP = 1.013 * 10 ** 5                    # :89
+
+
+def dae_solve_batch(p0_all, y0_all, tf=75.0, rtol=1e-6, atol=1e-6, h0=1e-5, want_states=False, device=0):
+    """Integrate n independent (particle, experiment) DAE solves on the GPU (K8, parity unpinned).
+    p0_all (n, 18), y0_all (n, 357) -> flows (n, 5), status (n,), states (n, 357) | None, info dict."""
+    p0_all = np.ascontiguousarray(np.atleast_2d(p0_all), dtype=np.float64)
+    y0_all = np.ascontiguousarray(np.atleast_2d(y0_all), dtype=np.float64)
+    n = p0_all.shape[0]
+    assert p0_all.shape == (n, NPAR) and y0_all.shape == (n, NSTATE)
+    flows = np.empty((n, 5))
+    status = np.empty(n, dtype=np.int32)
+    states = np.empty((n, NSTATE)) if want_states else None
+    stats = np.zeros(4, dtype=np.int64)
+    ms = B.ctypes.c_double(0)
+    _ck(lib().smc_meth_dae_host(device, _dp(p0_all), _dp(y0_all), n, tf, rtol, atol, h0, S_AREA, P_STP, _dp(flows),
+                                _dp(states) if want_states else None, status.ctypes.data_as(B.ctypes.POINTER(B.ctypes.c_int32)),
+                                stats.ctypes.data_as(B.c_i64p), B.ctypes.byref(ms)), "smc_meth_dae_host")
+    info = {"steps": int(stats[0]), "rejects": int(stats[1]), "newton_fail": int(stats[2]), "newton_iters": int(stats[3]),
+            "kernel_ms": ms.value}
+    return flows, status, states, info

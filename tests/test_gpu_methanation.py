@@ -71,3 +71,59 @@ def test_loglike(pkg, gold):
     ref = np.array([np.sum([-(0.5 / s ** 2) * np.sum((y[i] - gold["ll_d"][0][i]) ** 2) - nd * np.log(s) for i in range(5)])
                     for y, s in zip(ys, sig)])
     assert np.allclose(got, ref, rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# K8: DAE time integration (PARITY UNPINNED against the reference's IDA; compared with the oracle's
+# implementation of the same algorithm and checked for physical consistency)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cond_guess(M):
+    cond = M.load_conditions(os.path.join(GOLD, "methanation_information.csv"))
+    return cond, M.initial_guess(cond)
+
+
+def test_dae_batch_vs_oracle(pkg, M, cond_guess):
+    """30 experiments x 3 parameter vectors.  Tolerance: the oracle builds its iteration matrix by finite
+    differences and solves with a pivoted banded LU, the kernel uses the analytic matrix and a block LU, so the
+    Newton iterates differ below the Newton tolerance; both integrate to rtol = atol = 1e-6.  Outlet values
+    must agree within 20 tolerance units atol + rtol*|y| (observed: < 1e-3 units at the base parameters)."""
+    cond, guess = cond_guess
+    lo, hi, pos = M.prior_box()
+    rs = np.random.RandomState(3)
+    prs = [M.BASEPARAMS.copy()]
+    for _ in range(2):
+        pr = M.BASEPARAMS.copy()
+        pr[:4] = (lo[pos] + (hi[pos] - lo[pos]) * rs.uniform(0.2, 0.8, 5))[:4]
+        prs.append(pr)
+    p0 = np.array([M.p0_tuple(cond, i, pr) for pr in prs for i in range(30)])
+    y0 = np.array([guess[i] for pr in prs for i in range(30)])
+    flows, status, states, info = pkg.methanation.dae_solve_batch(p0, y0, want_states=True)
+    assert np.all(status == 0)
+    outlet = [50, 101, 152, 203, 254, 305, 356]
+    worst = 0.0
+    for k in range(len(p0)):
+        yo, rc, st = M.dae_solve(y0[k], p0[k])
+        assert rc == 0
+        units = np.abs(states[k] - yo)[outlet] / (1e-6 + 1e-6 * np.abs(yo[outlet]))
+        worst = max(worst, units.max())
+    assert worst < 20, worst
+    # flows follow from the outlet state by my_model's mapping (:204-208)
+    fo, _, _ = M.my_model(prs[0], cond, guess)
+    assert np.allclose(flows[:30].T, fo, rtol=1e-4, atol=1e-3)
+    assert 150 * len(p0) < info["steps"] < 1000 * len(p0)
+
+
+def test_dae_physics_and_failure_sentinel(pkg, M, cond_guess):
+    cond, guess = cond_guess
+    p0 = np.array([M.p0_tuple(cond, i, M.BASEPARAMS) for i in range(30)])
+    flows, status, _, info = pkg.methanation.dae_solve_batch(p0, guess)
+    info_tab = np.loadtxt(os.path.join(GOLD, "methanation_information.csv"), delimiter=",", skiprows=1)[:30]
+    assert np.all(status == 0) and np.all(flows > 0)
+    assert np.allclose(flows[:, 1] + flows[:, 2], info_tab[:, 11], rtol=2e-2)   # carbon balance
+    assert np.allclose(flows[:, 4], info_tab[:, 15], rtol=2e-2)                 # argon is inert
+    # an unsolvable case (NaN kinetic parameter) must come back as the reference's sentinel -10000
+    bad = p0[:1].copy()
+    bad[0, 10] = np.nan
+    f2, st2, _, _ = pkg.methanation.dae_solve_batch(bad, guess[:1])
+    assert st2[0] != 0 and np.all(f2 == -10000.0)
