@@ -29,8 +29,10 @@
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 #define SMC_HD __host__ __device__ __forceinline__
+#define SMC_UNROLL _Pragma("unroll")
 #else
 #define SMC_HD inline
+#define SMC_UNROLL
 #endif
 
 namespace smc {
@@ -107,8 +109,10 @@ SMC_HD void node_eval(int i, const double *wm, const double *w0, const double *w
     const double P0 = p[0] * k::R * T_in + p[1] * k::R * T_in + p[2] * k::R * T_in + p[3] * k::R * T_in + p[4] * k::R * T_in;
     const double T_jacket = p[6], u_in = p[7], vd = p[8], dz = p[9];
     if (JAC)
+        SMC_UNROLL
         for (int q = 0; q < kNB; ++q) Lb[q] = Db[q] = Ub[q] = 0.0;
     if (i == 0) {  // :96-102
+        SMC_UNROLL
         for (int f = 0; f < 6; ++f) {
             res[f] = yd0[f];
             if (JAC) Db[f * 7 + f] = cj;
@@ -118,6 +122,7 @@ SMC_HD void node_eval(int i, const double *wm, const double *w0, const double *w
         return;
     }
     if (i == kNX - 1) {  // :130-137 (u equation sits in the T slot of the reference, T equation in the u slot)
+        SMC_UNROLL
         for (int f = 0; f < 5; ++f) {
             res[f] = w0[f] - wm[f];
             if (JAC) { Db[f * 7 + f] = 1.0; Lb[f * 7 + f] = -1.0; }
@@ -133,12 +138,14 @@ SMC_HD void node_eval(int i, const double *wm, const double *w0, const double *w
     const double r = rate_and_grad(Ti, w0[0], w0[1], w0[2], w0[3], p + 10, g);
     const double sc[5] = {-4, -1, 1, 2, 0};
     const double dif = vd * k::Dz / dz2;
+    SMC_UNROLL
     for (int f = 0; f < 5; ++f) {  // :105-109 / :115-119
         const double ci = w0[f], cm = wm[f], cp = wp[f];
         const double diff = (i == 1) ? (cp - ci) : (cp - 2 * ci + cm);
         res[f] = -vd * yd0[f] - (ui * ci - um * cm) / dz + vd * k::Dz * diff / dz2 + (1 - vd) * sc[f] * r;
         if (JAC) {
             const double rs = (1 - vd) * sc[f];
+            SMC_UNROLL
             for (int gg = 0; gg < 4; ++gg) Db[f * 7 + gg] = rs * g[gg];
             Db[f * 7 + f] += -vd * cj - ui / dz - ((i == 1) ? dif : 2 * dif);
             Db[f * 7 + 5] = rs * g[4];
@@ -168,6 +175,7 @@ SMC_HD void node_eval(int i, const double *wm, const double *w0, const double *w
         const double mw[5] = {2, 44, 16, 18, 40};
         const double drg_dT = -rg / Ti;
         const double he = (1 - vd) * (-k::Hr);
+        SMC_UNROLL
         for (int gg = 0; gg < 5; ++gg) {
             const double drg = pref * 0.001 * (mw[gg] * Ssum - Nsum) / (Ssum * Ssum);
             Db[5 * 7 + gg] = -kap * vd * k::Cpg * drg * dT - k::Cpg * drg * conv / dz + ((gg < 4) ? he * g[gg] : 0.0);
@@ -179,6 +187,7 @@ SMC_HD void node_eval(int i, const double *wm, const double *w0, const double *w
         Lb[5 * 7 + 6] = rg * k::Cpg * Tm / dz;
         Ub[5 * 7 + 5] = k::Keff / dz2;
         const double ht = (1 - vd) * k::R * (-2);
+        SMC_UNROLL
         for (int gg = 0; gg < 4; ++gg) Db[6 * 7 + gg] = ht * g[gg];
         Db[6 * 7 + 5] = -ui * P0 * (-1 / (Ti * Ti)) / dz + P0 / (Ti * Ti) * (ui - um) / dz + dif * P0 * (2 / (Ti * Ti)) + ht * g[4];
         if (i == 1) Db[6 * 7 + 5] += P0 * vd * (-2.0 / (Ti * Ti * Ti) * dT + cj / (Ti * Ti));
@@ -189,50 +198,79 @@ SMC_HD void node_eval(int i, const double *wm, const double *w0, const double *w
     }
 }
 
-// 7x7 LU without pivoting, in place (unit lower).  Returns false on a zero / non-finite pivot.
+// 7x7 LU without pivoting, in place (unit lower; the diagonal stores 1/pivot).  Returns false on a zero /
+// non-finite pivot.
 SMC_HD bool lu7(double *a) {
+    SMC_UNROLL
     for (int kk = 0; kk < 7; ++kk) {
         const double piv = a[kk * 7 + kk];
         if (!(fabs(piv) > 1e-300) || !(fabs(piv) < 1e300)) return false;
         const double inv = 1.0 / piv;
+        a[kk * 7 + kk] = inv;  // the diagonal holds the RECIPROCAL pivot: no divisions in the solves
+        SMC_UNROLL
         for (int r = kk + 1; r < 7; ++r) {
             const double l = a[r * 7 + kk] * inv;
             a[r * 7 + kk] = l;
+            SMC_UNROLL
             for (int c = kk + 1; c < 7; ++c) a[r * 7 + c] -= l * a[kk * 7 + c];
         }
     }
     return true;
 }
 SMC_HD void lu7_solve(const double *lu, double *b) {  // b <- (LU)^{-1} b
+    SMC_UNROLL
     for (int r = 1; r < 7; ++r)
+        SMC_UNROLL
         for (int c = 0; c < r; ++c) b[r] -= lu[r * 7 + c] * b[c];
+    SMC_UNROLL
     for (int r = 6; r >= 0; --r) {
+        SMC_UNROLL
         for (int c = r + 1; c < 7; ++c) b[r] -= lu[r * 7 + c] * b[c];
-        b[r] /= lu[r * 7 + r];
+        b[r] *= lu[r * 7 + r];
     }
 }
 SMC_HD void lu7_rsolve(const double *lu, double *x) {  // x <- x (LU)^{-1}  (row vector)
+    SMC_UNROLL
     for (int c = 0; c < 7; ++c) {
+        SMC_UNROLL
         for (int q = 0; q < c; ++q) x[c] -= x[q] * lu[q * 7 + c];
-        x[c] /= lu[c * 7 + c];
+        x[c] *= lu[c * 7 + c];
     }
+    SMC_UNROLL
     for (int c = 5; c >= 0; --c)
+        SMC_UNROLL
         for (int q = c + 1; q < 7; ++q) x[c] -= x[q] * lu[q * 7 + c];
 }
 
-struct BdfConst {
-    double gamma[6], alpha[6], error_const[7];
-};
-SMC_HD BdfConst bdf_constants() {
-    const double kappa[6] = {0, -0.1850, -1.0 / 9, -0.0823, -0.0415, 0};
-    BdfConst c;
-    c.gamma[0] = 0.0;
-    for (int q = 1; q <= kMaxOrder; ++q) c.gamma[q] = c.gamma[q - 1] + 1.0 / q;
-    for (int q = 0; q <= kMaxOrder; ++q) c.alpha[q] = (1 - kappa[q]) * c.gamma[q];
-    for (int q = 0; q <= kMaxOrder; ++q) c.error_const[q] = kappa[q] * c.gamma[q] + 1.0 / (q + 1);
-    c.error_const[kMaxOrder + 1] = 1.0 / (kMaxOrder + 2);
-    return c;
+// BDF/NDF constants (bdf.py:247-250): gamma_k = sum_{j<=k} 1/j, alpha_k = (1 - kappa_k) gamma_k,
+// error_const_k = kappa_k gamma_k + 1/(k+1), kappa = (0, -0.1850, -1/9, -0.0823, -0.0415, 0).
+// Looked up with a switch: a table held in registers and indexed with the run-time order makes hipcc emit
+// a waterfall loop (s_set_gpr_idx) per access.
+SMC_HD double bdf_gamma(int q) {
+    switch (q) {
+        case 0: return 0.0;
+        case 1: return 1.0;
+        case 2: return 1.0 + 1.0 / 2;
+        case 3: return 1.0 + 1.0 / 2 + 1.0 / 3;
+        case 4: return 1.0 + 1.0 / 2 + 1.0 / 3 + 1.0 / 4;
+        default: return 1.0 + 1.0 / 2 + 1.0 / 3 + 1.0 / 4 + 1.0 / 5;
+    }
 }
+SMC_HD double bdf_kappa(int q) {
+    switch (q) {
+        case 1: return -0.1850;
+        case 2: return -1.0 / 9;
+        case 3: return -0.0823;
+        case 4: return -0.0415;
+        default: return 0.0;
+    }
+}
+SMC_HD double bdf_alpha(int q) { return (1 - bdf_kappa(q)) * bdf_gamma(q); }
+SMC_HD double bdf_error_const(int q) { return (q <= kMaxOrder ? bdf_kappa(q) * bdf_gamma(q) : 0.0) + 1.0 / (q + 1); }
+struct BdfConst {
+    int unused;
+};
+SMC_HD BdfConst bdf_constants() { return BdfConst{0}; }
 
 // bdf.py compute_R / change_D: rescale the differences array for a step-size change by `factor`
 SMC_HD void change_D(const Ws &ws, int order, double factor) {
@@ -366,13 +404,14 @@ SMC_HD double newton_iteration(const Ws &ws, const double *p, double c, double r
 // Integrate one solve from y0 (already stored in D[0]; the other rows of D are zero) to tf.
 SMC_HD void dae_integrate(const Ws &ws, const double *p, double tf, double rtol, double atol, double h0, int max_attempts,
                           DaeStats &st) {
-    const BdfConst bc = bdf_constants();
     const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
     st.status = 0;
     double t = 0.0, h_abs = h0;
     int order = 1, n_equal = 0, attempts = 0;
     while (t < tf) {  // one iteration = one step attempt
+        // give up on a vanishing step or when the attempt budget (about 7x what a healthy solve needs) is spent:
+        // status 1 -> the reference's -10000 sentinel (:244-249)
         if (h_abs < 1e-14 * fmax(1.0, t) || attempts >= max_attempts) { st.status = 1; return; }
         ++attempts;
         double t_new = t + h_abs;
@@ -383,15 +422,15 @@ SMC_HD void dae_integrate(const Ws &ws, const double *p, double tf, double rtol,
         }
         const double h = t_new - t;
         h_abs = fabs(h);
-        const double c = h / bc.alpha[order];
+        const double c = h / bdf_alpha(order);
         // predictor, psi; Newton start
         for (int x = 0; x < kNS; ++x) {
             double s = 0.0, q = 0.0;
             for (int kk = 0; kk <= order; ++kk) s += ws(OFF_D + kk * kNS + x);
-            for (int kk = 1; kk <= order; ++kk) q += ws(OFF_D + kk * kNS + x) * bc.gamma[kk];
+            for (int kk = 1; kk <= order; ++kk) q += ws(OFF_D + kk * kNS + x) * bdf_gamma(kk);
             ws(OFF_YP + x) = s;
             ws(OFF_Y + x) = s;
-            ws(OFF_PSI + x) = q / bc.alpha[order];
+            ws(OFF_PSI + x) = q / bdf_alpha(order);
             ws(OFF_DD + x) = 0.0;
         }
         ++st.nlu;
@@ -424,13 +463,13 @@ SMC_HD void dae_integrate(const Ws &ws, const double *p, double tf, double rtol,
         double se = 0.0;
         for (int x = 0; x < 6 * kNX; ++x) {
             const double sc = atol + rtol * fabs(ws(OFF_Y + x));
-            const double e = bc.error_const[order] * ws(OFF_DD + x) / sc;
+            const double e = bdf_error_const(order) * ws(OFF_DD + x) / sc;
             se += e * e;
         }
         const double error_norm = sqrt(se / (6 * kNX));
-        if (error_norm > 1) {
+        if (!(error_norm <= 1)) {
             ++st.rejects;
-            const double factor = fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1)));
+            const double factor = (error_norm == error_norm) ? fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1))) : 0.2;
             h_abs *= factor;
             change_D(ws, order, factor);
             n_equal = 0;
@@ -456,8 +495,8 @@ SMC_HD void dae_integrate(const Ws &ws, const double *p, double tf, double rtol,
             }
             if (select && x < 6 * kNX) {
                 const double sc = atol + rtol * fabs(ws(OFF_Y + x));
-                if (order > 1) { const double e = bc.error_const[order - 1] * d_order / sc; sm += e * e; }
-                if (order < kMaxOrder) { const double e = bc.error_const[order + 1] * dnew2 / sc; sp += e * e; }
+                if (order > 1) { const double e = bdf_error_const(order - 1) * d_order / sc; sm += e * e; }
+                if (order < kMaxOrder) { const double e = bdf_error_const(order + 1) * dnew2 / sc; sp += e * e; }
             }
         }
         if (!select) continue;

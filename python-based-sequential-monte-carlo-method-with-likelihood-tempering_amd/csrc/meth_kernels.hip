@@ -4,10 +4,12 @@
 // points operating on host buffers.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "../../include/smc_hip.h"
 #include "meth_dae.h"
+#include "meth_dae_wave.h"
 #include "meth_model.h"
 
 namespace smc {
@@ -94,6 +96,45 @@ dae_kernel(double *__restrict__ wsbuf, int64_t nslots, const double *__restrict_
         atomicAdd(&counters[1], (unsigned long long)st.rejects);
         atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
         atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
+    }
+}
+
+// K8 v2: one wave per solve, lane = axial node (meth_dae_wave.h).  Persistent waves walk the solve list.
+__global__ void __launch_bounds__(64)
+dae_wave_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0_all, int64_t n_solves, double tf,
+                double rtol, double atol, double h0, int max_attempts, double S, double P_stp,
+                double *__restrict__ flows, double *__restrict__ y_final, int *__restrict__ status,
+                unsigned long long *__restrict__ counters) {
+    extern __shared__ double sD[];  // 8 x 7 x 64
+    const int lane = threadIdx.x;
+    const DView D{sD, lane};
+    for (int64_t sidx = blockIdx.x; sidx < n_solves; sidx += gridDim.x) {
+        double p[18];
+        for (int q = 0; q < 18; ++q) p[q] = p0_all[sidx * 18 + q];
+        if (lane < kNX)
+            for (int f = 0; f < 7; ++f) {
+                D(0, f) = y0_all[sidx * kNS + f * kNX + lane];
+                for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
+            }
+        DaeStats st;
+        dae_wave_integrate(sD, lane, p, tf, rtol, atol, h0, max_attempts, st);
+        if (lane == kNX - 1) {
+            const double u = D(0, 6), T = D(0, 5);
+            const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
+            for (int f = 0; f < 5; ++f) {
+                const double cc = D(0, f);
+                flows[sidx * 5 + f] = (st.status == 0)
+                                          ? cc * S * u * 60 * k::R * T / (P_total) * 1e6 * (P_total) / P_stp * 298 / T
+                                          : -10000.0;
+            }
+            status[sidx] = st.status;
+            atomicAdd(&counters[0], (unsigned long long)st.steps);
+            atomicAdd(&counters[1], (unsigned long long)st.rejects);
+            atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
+            atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
+        }
+        if (y_final && lane < kNX)
+            for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + lane] = D(0, f);
     }
 }
 
@@ -187,13 +228,14 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipSetDevice(device));
     hipDeviceProp_t prop;
     MH(hipGetDeviceProperties(&prop, device));
+    const bool v1 = getenv("SMC_METH_DAE_V1") != nullptr;   // debug: the thread-per-solve version (meth_dae.h)
     int64_t nslots = ((n_solves + 63) / 64) * 64;
     const int64_t max_slots = (int64_t)prop.multiProcessorCount * 256;   // 4 waves per CU
     if (nslots > max_slots) nslots = max_slots;
-    double *dws, *dp, *dy0, *dfl, *dyf = nullptr;
+    double *dws = nullptr, *dp, *dy0, *dfl, *dyf = nullptr;
     int *dst;
     unsigned long long *dcnt;
-    MH(hipMalloc(&dws, (size_t)nslots * kWsDoubles * sizeof(double))); bufs.push_back(dws);
+    if (v1) { MH(hipMalloc(&dws, (size_t)nslots * kWsDoubles * sizeof(double))); bufs.push_back(dws); }
     MH(hipMalloc(&dp, (size_t)n_solves * 18 * 8)); bufs.push_back(dp);
     MH(hipMalloc(&dy0, (size_t)n_solves * kNS * 8)); bufs.push_back(dy0);
     MH(hipMalloc(&dfl, (size_t)n_solves * 5 * 8)); bufs.push_back(dfl);
@@ -207,8 +249,15 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipEventCreate(&e0));
     MH(hipEventCreate(&e1));
     MH(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(dae_kernel, dim3((unsigned)(nslots / 64)), dim3(64), 0, 0, dws, nslots, dp, dy0, n_solves, tf, rtol,
-                       atol, h0, 20000, S, P_stp, dfl, dyf, dst, dcnt);
+    if (v1) {
+        hipLaunchKernelGGL(dae_kernel, dim3((unsigned)(nslots / 64)), dim3(64), 0, 0, dws, nslots, dp, dy0, n_solves, tf,
+                           rtol, atol, h0, 3000, S, P_stp, dfl, dyf, dst, dcnt);
+    } else {
+        int64_t nwaves = (int64_t)prop.multiProcessorCount * 4;
+        if (nwaves > n_solves) nwaves = n_solves;
+        hipLaunchKernelGGL(dae_wave_kernel, dim3((unsigned)nwaves), dim3(64), 8 * 7 * 64 * sizeof(double), 0, dp, dy0,
+                           n_solves, tf, rtol, atol, h0, 3000, S, P_stp, dfl, dyf, dst, dcnt);
+    }
     MH(hipGetLastError());
     MH(hipEventRecord(e1, 0));
     MH(hipEventSynchronize(e1));
