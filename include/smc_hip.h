@@ -66,6 +66,15 @@ int smc_device_info(smc_ctx *ctx, char *name, int name_len, char *arch, int arch
  * n_ex x n_t row-major, S0 has n_ex entries.  n_ex <= 16, n_t <= 256. */
 int smc_set_model_mm(smc_ctx *ctx, const double *t, const double *P_obs, const double *S0, int n_ex, int n_t,
                      int est_sigma, double sigma_fixed, double rtol, double atol);
+/* Methanation model (configs 4-5) for the resident sets: smc_loglik and smc_mh_step_* then evaluate
+ * cal_parallel_new (methanation_functions.py:44-65) per particle: the particle's `dim` estimated values are
+ * scattered into the 9-vector base_params at est_position (:80), my_model integrates the DAE of each of the
+ * n_data experiments (K8, parity unpinned against IDA) and my_loglike compares the outlet flows with obs.
+ * cond: n_data x 10 (Ca_in,Cb_in,Cc_in,Cd_in,Ce_in,T_in,T_jacket,u_in,void,dz = the first ten entries of p0,
+ * methanation_set_likelihood.py:164); guess: n_data x 357; obs: 5 x n_data; base_params: 9. */
+int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *guess, const double *obs, int n_data,
+                              const double *base_params, const int *est_position, int est_sigma, double sigma_fixed,
+                              double tf, double rtol, double atol);
 /* Independent priors, one per parameter: kind[i] in {SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL}; (a,b) =
  * (low,high) or (mu,sigma).  Used by the support mask of cal_prior (Micmem_SMC_main.py:60-90,
  * 224-228) and by smc_sample_prior_device. */

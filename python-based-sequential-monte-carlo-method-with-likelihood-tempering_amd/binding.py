@@ -41,6 +41,7 @@ SIGNATURES = {
     "smc_synchronize": (cint, [c_ctx]),
     "smc_device_info": (cint, [c_ctx, ctypes.c_char_p, cint, ctypes.c_char_p, cint, c_ip]),
     "smc_set_model_mm": (cint, [c_ctx, c_dp, c_dp, c_dp, cint, cint, cint, f64, f64, f64]),
+    "smc_set_model_methanation": (cint, [c_ctx, c_dp, c_dp, c_dp, cint, c_dp, c_ip, cint, f64, f64, f64, f64]),
     "smc_set_prior": (cint, [c_ctx, c_ip, c_dp, c_dp, cint]),
     "smc_upload_particles": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_download_particles": (cint, [c_ctx, cint, c_dp, i64]),

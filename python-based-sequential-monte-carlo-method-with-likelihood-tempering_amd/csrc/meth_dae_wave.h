@@ -14,7 +14,7 @@
 //     z_i = D'_i^{-1}(b_i - L_i z_{i-1}) forward, x_i = z_i - G_i x_{i+1} backward.  Values travel between
 //     neighbouring lanes with v_readlane (the source lane index is wave-uniform).
 // The time-stepping logic (variable-order BDF/NDF, Newton, error control) is that of meth_dae.h, which is
-// unit-tested on the CPU (tests/hostcheck) and against the oracle; all control decisions here derive from
+// unit-tested on the CPU (tests/hostcheck) and against the CPU checker; all control decisions here derive from
 // wave-reduced norms, so they are uniform across the wave.  PARITY UNPINNED against the reference's IDA.
 #pragma once
 #include <hip/hip_runtime.h>

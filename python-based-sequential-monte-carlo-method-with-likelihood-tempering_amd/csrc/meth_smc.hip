@@ -1,0 +1,212 @@
+// meth_smc.hip -- the methanation model inside the SMC loop (configs 4-5): likelihood sweep and Metropolis
+// iteration on the resident particle sets.  Same three-stage shape as the Michaelis-Menten sweep
+// (mm_kernels.hip): propose -> solve -> accept, where "solve" is K8, the DAE time integration of every
+// (particle, experiment) pair (meth_dae_wave.h; PARITY UNPINNED against the reference's IDA), followed by
+// my_loglike (methanation_set_likelihood.py:280-300) per particle.
+//   sim_particle / cal_parallel_new   methanation_functions.py:44-92
+//   MH iteration                       SMC_methanation_main.py:295-391 (the taken branch: normal_pred False)
+#include <hip/hip_runtime.h>
+
+#include "meth_dae_wave.h"
+#include "philox.h"
+#include "prior.h"
+#include "smc_internal.h"
+
+namespace smc {
+
+using namespace meth;
+
+// K8 over (particle, experiment) pairs of the resident set; one wave per solve, persistent waves.
+__global__ void __launch_bounds__(64)
+meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
+                          const uint8_t *__restrict__ p0mask, double *__restrict__ flows, int *__restrict__ status,
+                          SweepCounters *__restrict__ counters) {
+    extern __shared__ double sD[];
+    const int lane = threadIdx.x;
+    const DView D{sD, lane};
+    const int64_t total = n * m.n_data;
+    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+        const int64_t particle = w / m.n_data;
+        const int e = (int)(w - particle * m.n_data);
+        if (p0mask && p0mask[particle] == 0) continue;   // masked proposal: lk2 == lk1, nothing to solve
+        double p[18];
+        for (int q = 0; q < 10; ++q) p[q] = m.cond[e * 10 + q];
+        for (int j = 0; j < 8; ++j) {  // p_pred_bases[:, est_position] = particle (methanation_functions.py:80)
+            double v = m.base[j];
+            for (int kq = 0; kq < m.dim; ++kq)
+                if (m.est_pos[kq] == j) v = theta[kq * stride + particle];
+            p[10 + j] = v;
+        }
+        if (lane < kNX)
+            for (int f = 0; f < 7; ++f) {
+                D(0, f) = m.guess[(int64_t)e * kNS + f * kNX + lane];
+                for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
+            }
+        DaeStats st;
+        dae_wave_integrate(sD, lane, p, m.tf, m.rtol, m.atol, m.h0, 3000, st);
+        if (lane == kNX - 1) {
+            const double u = D(0, 6), T = D(0, 5);
+            const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
+            for (int f = 0; f < 5; ++f) {
+                const double cc = D(0, f);
+                flows[w * 5 + f] = (st.status == 0)
+                                       ? cc * m.S * u * 60 * k::R * T / (P_total) * 1e6 * (P_total) / m.P_stp * 298 / T
+                                       : -10000.0;   // methanation_set_likelihood.py:244-249
+            }
+            status[w] = st.status;
+            atomicAdd(&counters->rk_attempts, (unsigned long long)st.steps);
+        }
+    }
+}
+
+// my_loglike per particle from its 5 x n_data flows (:280-300); sigma = the particle's last estimated parameter
+// when est_sigma (methanation_functions.py:50-53)
+__global__ void meth_particle_loglike_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
+                                             const double *__restrict__ flows, double *__restrict__ lk) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double sigma = m.sigma_fixed;
+    if (m.est_sigma) {
+        sigma = m.base[8];
+        for (int kq = 0; kq < m.dim; ++kq)
+            if (m.est_pos[kq] == 8) sigma = theta[kq * stride + p];
+    }
+    const double c = -(0.5 / (sigma * sigma)), l = m.n_data * log(sigma);
+    double total = 0.0;
+    for (int i = 0; i < 5; ++i) {
+        double acc = 0.0;
+        for (int e = 0; e < m.n_data; ++e) {
+            const double d = flows[(p * m.n_data + e) * 5 + i] - m.obs[i * m.n_data + e];
+            acc += d * d;
+        }
+        total += c * acc - l;
+    }
+    lk[p] = total;
+}
+
+// proposal + support mask for any dimension d <= SMC_MAX_DIM (SMC_methanation_main.py:312-336 /
+// Micmem_SMC_main.py:220-228)
+__global__ void __launch_bounds__(256)
+generic_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int64_t stride, int64_t n, int d,
+                       double *__restrict__ prop, int64_t pstride, uint8_t *__restrict__ p0_out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    double z[SMC_MAX_DIM], g[SMC_MAX_DIM];
+    if (mh.device_rng) {
+        const uint64_t gi = (uint64_t)(mh.global_offset + p);
+        for (int b = 0; b < (SMC_MAX_DIM + 1) / 2; ++b) {
+            if (2 * b >= d) break;
+            const u32x4 r = philox_block(mh.seed, gi, mh.stream, (uint32_t)b);
+            const double u1 = 1.0 - u01_from(r.x, r.y), u2 = u01_from(r.z, r.w);
+            const double rad = sqrt(-2.0 * log(u1));
+            double sn, cs;
+            sincos(6.283185307179586 * u2, &sn, &cs);
+            g[2 * b] = rad * cs;
+            if (2 * b + 1 < SMC_MAX_DIM) g[2 * b + 1] = rad * sn;
+        }
+        for (int c = 0; c < d; ++c) {
+            double s = 0.0;
+            for (int kq = 0; kq < d; ++kq) s += g[kq] * mh.transform[kq * d + c];
+            z[c] = s;
+        }
+    } else {
+        for (int c = 0; c < d; ++c) z[c] = mh.noise[(int64_t)c * n + p];
+    }
+    double pdf = 1.0, cand[SMC_MAX_DIM], cur[SMC_MAX_DIM];
+    for (int c = 0; c < d; ++c) {
+        cur[c] = filt[c * stride + p];
+        cand[c] = __dadd_rn(cur[c], __dmul_rn(z[c], mh.ratio));
+        const double q = prior_pdf(prior.kind[c], prior.a[c], prior.b[c], cand[c]);
+        pdf = (c == 0) ? q : pdf * q;
+    }
+    const double p0 = (pdf > 0.0) ? 1.0 : 0.0, q0 = 1.0 - p0;
+    for (int c = 0; c < d; ++c) prop[c * pstride + p] = __dadd_rn(__dmul_rn(cand[c], p0), __dmul_rn(cur[c], q0));
+    p0_out[p] = (uint8_t)(p0 != 0.0);
+}
+
+// accept / select for any dimension, from a precomputed lk2 array
+__global__ void __launch_bounds__(256)
+generic_accept_kernel(MHParams mh, const double *__restrict__ prop, int64_t pstride, int64_t n, int d,
+                      const double *__restrict__ lk2_arr, const uint8_t *__restrict__ p0_in, double *lk_io, double *filt,
+                      int64_t fstride, uint8_t *__restrict__ r_ac, SweepCounters *__restrict__ counters,
+                      double *__restrict__ dbg_lk2, uint8_t *__restrict__ dbg_r) {
+    __shared__ unsigned long long s_cnt[4][2];
+    unsigned long long acc_now = 0, acc_ever = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const bool masked = p0_in[p] == 0;
+        const double lk1 = lk_io[p];
+        const double lk2 = masked ? lk1 : lk2_arr[p];
+        const double p0 = masked ? 0.0 : 1.0;
+        double rr;
+        if (mh.device_rng) {
+            const u32x4 ru = philox_block(mh.seed, (uint64_t)(mh.global_offset + p), mh.stream, SMC_PHILOX_BLOCK_UNIFORM);
+            rr = u01_from(ru.x, ru.y);
+        } else {
+            rr = mh.rr[p];
+        }
+        const double pp = exp((lk2 - lk1) * mh.gamma) * p0;
+        const double r = (pp >= rr) ? 1.0 : 0.0, nr = 1.0 - r;
+        for (int c = 0; c < d; ++c) {
+            const double th = prop[c * pstride + p], f = filt[c * fstride + p];
+            filt[c * fstride + p] = __dadd_rn(__dmul_rn(th, r), __dmul_rn(f, nr));
+        }
+        lk_io[p] = __dadd_rn(__dmul_rn(lk2, r), __dmul_rn(lk1, nr));
+        const uint8_t ever = (uint8_t)(r_ac[p] | (uint8_t)(r != 0.0));
+        r_ac[p] = ever;
+        acc_now += (r != 0.0);
+        acc_ever += ever;
+        if (dbg_lk2) {
+            dbg_lk2[p] = lk2;
+            dbg_r[p] = (uint8_t)(r != 0.0);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        acc_now += __shfl_down(acc_now, off);
+        acc_ever += __shfl_down(acc_ever, off);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[w][0] = acc_now;
+        s_cnt[w][1] = acc_ever;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned long long v = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        if (v) atomicAdd(threadIdx.x == 0 ? &counters->accepted_now : &counters->accepted_ever, v);
+    }
+}
+
+static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask) {
+    const MethModel &m = ctx->meth;
+    int64_t nwaves = (int64_t)ctx->cu_count * 4;
+    if (nwaves > n * m.n_data) nwaves = n * m.n_data;
+    if (nwaves < 1) nwaves = 1;
+    ScopedTimer tm(ctx, SMC_T_SOLVE);
+    hipLaunchKernelGGL(meth_particles_dae_kernel, dim3((unsigned)nwaves), dim3(64), 8 * 7 * 64 * sizeof(double), ctx->stream,
+                       m, theta, stride, n, p0mask, ctx->d_mflows, ctx->d_mstatus, ctx->d_counters);
+}
+
+void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk) {
+    if (n <= 0) return;
+    launch_solves(ctx, theta, stride, n, nullptr);
+    hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
+                       theta, stride, n, ctx->d_mflows, lk);
+}
+
+void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
+    if (n <= 0) return;
+    ParticleSet &F = ctx->set[SMC_SET_FILT];
+    ParticleSet &P = ctx->set[SMC_SET_PRED];
+    const bool dbg = ctx->debug_capture != 0;
+    hipLaunchKernelGGL(generic_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
+                       F.theta, F.stride, n, ctx->dim, P.theta, P.stride, ctx->d_p0);
+    launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0);
+    hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
+                       P.theta, P.stride, n, ctx->d_mflows, ctx->d_mlk2);
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(generic_accept_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, ctx->stream, mh, P.theta,
+                       P.stride, n, ctx->dim, ctx->d_mlk2, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac, ctx->d_counters,
+                       dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);
+}
+
+}  // namespace smc

@@ -26,25 +26,10 @@
 
 #include "mm_rk45.h"
 #include "philox.h"
+#include "prior.h"
 #include "smc_internal.h"
 
 namespace smc {
-
-// scipy.stats pdf of one independent prior at x (Micmem_SMC_main.py:71-85).
-//   uniform: support mask on the standardised value y = (x-loc)/scale, closed interval [0,1];
-//   normal : exp(-y^2/2)/sqrt(2*pi)/scale.
-__device__ __forceinline__ double prior_pdf(int kind, double a, double b, double x) {
-    if (kind == SMC_PRIOR_UNIFORM) {
-        const double scale = b - a;
-        const double y = (x - a) / scale;
-        if (x != x) return x;
-        return (y >= 0.0 && y <= 1.0 && scale > 0.0) ? 1.0 / scale : 0.0;
-    } else {
-        const double y = (x - a) / b;
-        if (!(b > 0.0)) return quiet_nan();
-        return exp(-(y * y) / 2.0) / 2.5066282746310002 / b;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // proposal (Micmem_SMC_main.py:220-228)

@@ -197,6 +197,12 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_info);
     (void)hipFree(c->d_p0);
     (void)hipFree(c->d_queue);
+    (void)hipFree(c->d_mcond);
+    (void)hipFree(c->d_mguess);
+    (void)hipFree(c->d_mobs);
+    (void)hipFree(c->d_mflows);
+    (void)hipFree(c->d_mlk2);
+    (void)hipFree(c->d_mstatus);
     (void)hipFree(c->d_hb_theta);
     (void)hipFree(c->d_hb_lk);
     (void)hipFree(c->d_hb_pred);
@@ -253,8 +259,45 @@ int smc_set_model_mm(smc_ctx *c, const double *t, const double *P_obs, const dou
     c->mm.rtol = rtol;
     c->mm.atol = atol;
     c->item_cap = 0;  // per-(experiment, particle) scratch is sized by n_ex
+    c->model_kind = 1;
     c->have_model = true;
     return ensure_item_capacity(c, c->n_local);
+}
+
+int smc_set_model_methanation(smc_ctx *c, const double *cond, const double *guess, const double *obs, int n_data,
+                              const double *base_params, const int *est_position, int est_sigma, double sigma_fixed,
+                              double tf, double rtol, double atol) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (n_data < 1 || n_data > 128) return fail(c, "n_data must be 1..128");
+    for (int q = 0; q < c->dim; ++q)
+        if (est_position[q] < 0 || est_position[q] > 8) return fail(c, "est_position entries must be 0..8");
+    HIPC(c, hipSetDevice(c->device));
+    (void)hipFree(c->d_mcond); (void)hipFree(c->d_mguess); (void)hipFree(c->d_mobs); (void)hipFree(c->d_mflows);
+    (void)hipFree(c->d_mlk2); (void)hipFree(c->d_mstatus);
+    c->d_mcond = c->d_mguess = c->d_mobs = c->d_mflows = c->d_mlk2 = nullptr;
+    c->d_mstatus = nullptr;
+    HIPC(c, hipMalloc(&c->d_mcond, (size_t)n_data * 10 * 8));
+    HIPC(c, hipMalloc(&c->d_mguess, (size_t)n_data * 357 * 8));
+    HIPC(c, hipMalloc(&c->d_mobs, (size_t)n_data * 5 * 8));
+    HIPC(c, hipMalloc(&c->d_mflows, (size_t)c->n_local * n_data * 5 * 8));
+    HIPC(c, hipMalloc(&c->d_mlk2, (size_t)c->n_local * 8));
+    HIPC(c, hipMalloc(&c->d_mstatus, (size_t)c->n_local * n_data * sizeof(int)));
+    HIPC(c, hipMemcpyAsync(c->d_mcond, cond, (size_t)n_data * 10 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->d_mguess, guess, (size_t)n_data * 357 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->d_mobs, obs, (size_t)n_data * 5 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMemsetAsync(c->d_mflows, 0, (size_t)c->n_local * n_data * 5 * 8, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    smc::MethModel &m = c->meth;
+    m.cond = c->d_mcond; m.guess = c->d_mguess; m.obs = c->d_mobs;
+    m.n_data = n_data; m.dim = c->dim; m.est_sigma = est_sigma;
+    for (int q = 0; q < 9; ++q) m.base[q] = base_params[q];
+    for (int q = 0; q < SMC_MAX_DIM; ++q) m.est_pos[q] = (q < c->dim) ? est_position[q] : -1;
+    m.sigma_fixed = sigma_fixed; m.tf = tf; m.rtol = rtol; m.atol = atol; m.h0 = 1e-5;
+    m.S = 3.141592653589793 * (0.01 / 2) * (0.01 / 2);   // methanation_set_conditon.py:80-81
+    m.P_stp = 1.013 * 100000;                            // :89
+    c->model_kind = 2;
+    c->have_model = true;
+    return 0;
 }
 
 int smc_set_prior(smc_ctx *c, const int *kind, const double *a, const double *b, int dim) {
@@ -371,7 +414,10 @@ int smc_loglik(smc_ctx *c, int set, int64_t *n_failed, int64_t *rk_attempts) {
     if (counters_begin(c)) return 1;
     {
         ScopedTimer tm(c, SMC_T_LOGLIK);
-        launch_mm_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk, nullptr);
+        if (c->model_kind == 2)
+            launch_meth_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk);
+        else
+            launch_mm_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk, nullptr);
     }
     HIPC(c, hipGetLastError());
     if (counters_end(c)) return 1;
@@ -383,7 +429,7 @@ int smc_loglik(smc_ctx *c, int set, int64_t *n_failed, int64_t *rk_attempts) {
 int smc_mm_loglik_host(smc_ctx *c, const double *particle, int64_t n, double *lk, double *pred, int64_t *n_failed,
                        int64_t *rk_attempts) {
     if (!c) return fail(nullptr, "NULL context");
-    if (!c->have_model) return fail(c, "smc_set_model_mm has not been called");
+    if (!c->have_model || c->model_kind != 1) return fail(c, "smc_set_model_mm has not been called");
     if (n < 0) return fail(c, "n < 0");
     HIPC(c, hipSetDevice(c->device));
     if (n_failed) *n_failed = 0;
@@ -701,7 +747,7 @@ int smc_mh_step_host_rng(smc_ctx *c, double gamma, double mhstep_ratio, const do
     mh.device_rng = 0;
     {
         ScopedTimer tm(c, SMC_T_MH);
-        launch_mm_mh(c, n, mh);
+        if (c->model_kind == 2) launch_meth_mh(c, n, mh); else launch_mm_mh(c, n, mh);
     }
     return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
 }
@@ -723,7 +769,7 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
     for (int i = 0; i < c->dim * c->dim; ++i) mh.transform[i] = transform[i];
     {
         ScopedTimer tm(c, SMC_T_MH);
-        launch_mm_mh(c, c->n_local, mh);
+        if (c->model_kind == 2) launch_meth_mh(c, c->n_local, mh); else launch_mm_mh(c, c->n_local, mh);
     }
     return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
 }

@@ -26,6 +26,16 @@ struct MMModel {     // passed by value to the sweep kernel
     double sigma_fixed, rtol, atol;
 };
 
+struct MethModel {   // methanation model (configs 4-5), passed by value to its kernels
+    const double *cond;   // n_data x 10: Ca_in,Cb_in,Cc_in,Cd_in,Ce_in,T_in,T_jacket,u_in,void,dz (the first 10 of p0, :164)
+    const double *guess;  // n_data x 357 initial states (SMC_methanation_main.py:47-58)
+    const double *obs;    // 5 x n_data observed flows (obs_data)
+    int n_data, dim, est_sigma;
+    double base[9];       // baseparams + sigma_true: values of the parameters that are not estimated
+    int est_pos[SMC_MAX_DIM];  // est_position (methanation_set_conditon.py:34)
+    double sigma_fixed, tf, rtol, atol, h0, S, P_stp;
+};
+
 struct Prior {       // passed by value
     int kind[SMC_MAX_DIM];
     double a[SMC_MAX_DIM], b[SMC_MAX_DIM];
@@ -71,6 +81,10 @@ struct smc_ctx {
     uint8_t *r_ac = nullptr;
 
     // model
+    int model_kind = 0;   // 0 none, 1 Michaelis-Menten, 2 methanation
+    smc::MethModel meth{};
+    double *d_mcond = nullptr, *d_mguess = nullptr, *d_mobs = nullptr, *d_mflows = nullptr, *d_mlk2 = nullptr;
+    int *d_mstatus = nullptr;
     bool have_model = false, have_prior = false;
     smc::MMModel mm{};
     double *d_t = nullptr, *d_P = nullptr, *d_S0 = nullptr;
@@ -128,6 +142,9 @@ namespace smc {
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred);
 void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
 int query_solve_blocks_per_cu();
+// implemented in meth_smc.hip
+void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);
+void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
 
 struct ScopedTimer {
     smc_ctx *c;

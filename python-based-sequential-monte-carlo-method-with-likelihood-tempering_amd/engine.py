@@ -85,6 +85,28 @@ class HipEngine:
                  "smc_set_model_mm")
         self.model = ("mm", t.shape[0], t.shape[1])
 
+    def set_model_methanation(self, cond, guess, obs, base_params, est_position, est_sigma=True, sigma_fixed=5.0,
+                              tf=75.0, rtol=1e-6, atol=1e-6):
+        """cond: dict with Ca_in..Ce_in, T_in, T_jacket, u_in, void, reactorlength (the reference's settings arrays,
+        methanation_set_conditon.py:141-214) or an (n_data, 10) array; guess (n_data, 357); obs (5, n_data)."""
+        if isinstance(cond, dict):
+            n_data = int(cond.get("n_data", len(cond["Ca_in"])))
+            cols = [np.asarray(cond[k], dtype=np.float64)[:n_data] for k in
+                    ("Ca_in", "Cb_in", "Cc_in", "Cd_in", "Ce_in", "T_in", "T_jacket", "u_in", "void")]
+            cols.append(np.asarray(cond["reactorlength"], dtype=np.float64)[:n_data] / (51 - 1))
+            cond = np.column_stack(cols)
+        cond = _f64(cond)
+        n_data = cond.shape[0]
+        guess = _f64(np.asarray(guess)[:n_data], (n_data, 357))
+        obs = _f64(obs, (5, n_data))
+        base = _f64(base_params, (9,))
+        pos = np.ascontiguousarray(est_position, dtype=np.int32)
+        assert pos.shape == (self.dim,)
+        self._ck(self.L.smc_set_model_methanation(self.ctx, _dp(cond), _dp(guess), _dp(obs), n_data, _dp(base),
+                                                  pos.ctypes.data_as(B.c_ip), int(bool(est_sigma)), float(sigma_fixed),
+                                                  float(tf), float(rtol), float(atol)), "smc_set_model_methanation")
+        self.model = ("methanation", n_data, 357)
+
     def set_prior(self, priors: dict):
         """priors: the reference's dict (Micmem_settings.py:55-67), one entry per parameter, in order."""
         kinds, a, b = [], [], []

@@ -127,3 +127,108 @@ def test_dae_physics_and_failure_sentinel(pkg, M, cond_guess):
     bad[0, 10] = np.nan
     f2, st2, _, _ = pkg.methanation.dae_solve_batch(bad, guess[:1])
     assert st2[0] != 0 and np.all(f2 == -10000.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the methanation model inside the SMC loop (config 4 at reduced N)
+# ---------------------------------------------------------------------------------------------------
+def _meth_settings(pkg, M, n):
+    lo, hi, pos = M.prior_box()
+    names = ["Af", "Eaf", "Ar", "Ear", "sigma"]
+    priors = {nm: {"dist": "uniform", "low": float(lo[i]), "high": float(hi[i])} for nm, i in zip(names, pos)}
+    return pkg.SMCSettings(n_particle=n, priors=priors, seed=20250205), pos
+
+
+def _meth_engine(pkg, M, cond, guess, obs, n):
+    s, pos = _meth_settings(pkg, M, n)
+    eng = pkg.HipEngine(n, 5, device=0)
+    eng.set_model_methanation(cond, guess, obs, np.append(M.BASEPARAMS, M.SIGMA_TRUE), pos)
+    eng.set_prior(s.priors)
+    return eng, s
+
+
+def test_methanation_loglik_sweep_and_mh_step_vs_oracle(pkg, M, cond_guess):
+    """sim_particle on the resident set and one Metropolis iteration (host-RNG mode) against the oracle's
+    my_model + my_loglike + cal_prior.  logL tolerance 1e-3 relative: K8 is compared with the oracle's
+    implementation of the same integrator (tolerance-level differences of the flows, sigma ~ 5)."""
+    cond, guess = cond_guess
+    rs = np.random.RandomState(4)
+    flows0, _, _ = M.my_model(M.BASEPARAMS, cond, guess)
+    obs = flows0 + 5.0 * rs.standard_normal(flows0.shape)
+    n = 6
+    eng, s = _meth_engine(pkg, M, cond, guess, obs, n)
+    lo, hi, pos = M.prior_box()
+    theta = lo[pos] + (hi[pos] - lo[pos]) * rs.uniform(0.25, 0.75, (n, 5))
+    theta[0] = np.append(M.BASEPARAMS, 5.0)[pos]
+
+    def oracle_lk(th):
+        out = np.empty(len(th))
+        for k, row in enumerate(th):
+            full = np.append(M.BASEPARAMS, M.SIGMA_TRUE).copy()
+            full[pos] = row
+            f, _, _ = M.my_model(full[:8], cond, guess)
+            out[k] = M.loglike(f, obs, full[8], 30)
+        return out
+    with eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, theta)
+        eng.upload_particles(pkg.SMC_SET_FILT, theta)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+        ref = oracle_lk(theta)
+        assert np.all(np.abs(lk - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref))), (lk, ref)
+        assert info["rk_attempts"] > 150 * n * 30
+        # one MH iteration with host-drawn noise; proposals 2 and 4 are pushed out of the prior box
+        eng.set_debug_capture(True)
+        eng.upload_lk(pkg.SMC_SET_FILT, lk)
+        noise = rs.standard_normal((n, 5)) * (hi[pos] - lo[pos]) * 0.02
+        noise[2, 0] = 1e9
+        noise[4, 4] = -1e9
+        rr = rs.uniform(0, 1, n)
+        gamma = 0.05
+        out = eng.mh_step_host_rng(gamma, 1.0, noise, rr)
+        prop, lk2, p0, r = eng.download_debug_proposals()
+        f = eng.download_particles(pkg.SMC_SET_FILT)
+        p_ref = theta + noise * 1.0
+        p0_ref = np.int32(M.cal_prior(p_ref) > 0)
+        p_ref = p_ref * p0_ref[:, None] + theta * (1.0 - p0_ref[:, None])
+        assert np.array_equal(p0, p0_ref) and p0_ref.tolist() == [1, 1, 0, 1, 0, 1]
+        assert np.array_equal(prop, p_ref)
+        lk2_ref = oracle_lk(p_ref)
+        live = p0_ref == 1
+        assert np.all(np.abs(lk2[live] - lk2_ref[live]) <= 1e-3 * np.maximum(1.0, np.abs(lk2_ref[live])))
+        assert np.array_equal(lk2[~live], lk[~live])                      # masked: lk2 is the stored lk1
+        with np.errstate(over="ignore"):
+            r_ref = np.int32(np.exp((lk2 - lk) * gamma) * p0_ref >= rr)   # decisions from the device's own lk2
+        assert np.array_equal(r, r_ref) and out["accepted_now"] == int(r_ref.sum())
+        assert np.array_equal(f, p_ref * r_ref[:, None] + theta * (1.0 - r_ref[:, None]))
+
+
+def test_methanation_full_smc_run_recovers_parameters(pkg, M, cond_guess):
+    """Config 4 at reduced size: synthetic observations = model at baseparams + sigma = 5 noise
+    (SMC_methanation_main.py:89-101), N = 192 particles, adaptive tempering to gamma = 1 on the device.
+    The posterior must concentrate around the generating parameters (a statistical check: the integrator is
+    parity-unpinned and N is small)."""
+    cond, guess = cond_guess
+    np.random.seed(20250205)
+    flows0, _, _ = M.my_model(M.BASEPARAMS, cond, guess)
+    obs = flows0.copy()
+    for i in range(5):
+        obs[i, :] = 1.0 * 5 * np.random.standard_normal(30) + obs[i, :]     # :94-95
+    n = 192
+    eng, s = _meth_engine(pkg, M, cond, guess, obs, n)
+    with eng:
+        out = pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=5)
+    assert out["gamma"] == 1.0 and 3 <= out["step"] <= 40
+    post = out["p_pred"]
+    lo, hi, pos = M.prior_box()
+    truth = np.append(M.BASEPARAMS, 5.0)[pos]
+    width = (hi - lo)[pos]
+    # the kinetic parameters are individually weakly identified (the reference's own saved N=1000 run shows the
+    # same); the noise level is well identified and none of the marginals is wider than the prior
+    assert np.all(post.std(axis=0) < 1.05 * width / np.sqrt(12))
+    assert abs(post[:, 4].mean() - 5.0) < 1.5 and post[:, 4].std() < 1.0   # sigma recovered
+    assert np.all(post >= lo[pos]) and np.all(post <= hi[pos])             # support mask respected
+    assert abs(post[:, 1].mean() - truth[1]) < 0.35 * width[1]              # activation energy of the forward step
+    # the likelihood at the posterior mean is close to the likelihood at the truth
+    assert out["lk"].max() > -0.5 * 150 - 150 * np.log(5.0) - 60
+    assert np.isfinite(out["logZ"])
