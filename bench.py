@@ -218,7 +218,7 @@ def main():
                                  "frac": hbm_gbps / HBM_PEAK_GBPS},
                          "mfma": "unused (largest contraction is 3x3)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
     comm.barrier()
