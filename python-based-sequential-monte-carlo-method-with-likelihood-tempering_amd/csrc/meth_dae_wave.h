@@ -239,6 +239,8 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
     double t = 0.0, h_abs = h0;
     int order = 1, n_equal = 0, attempts = 0;
     WaveBlocks B;
+    bool lu_valid = false, force_rebuild = false;
+    double c_lu = 0.0;
     double yp[7], y[7], psi[7], dd[7];
     while (t < tf) {  // one iteration = one step attempt (all quantities below are wave-uniform)
         if (h_abs < 1e-14 * fmax(1.0, t) || attempts >= max_attempts) { st.status = 1; return; }
@@ -265,10 +267,20 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
             psi[f] = q / bdf_alpha(order);
             dd[f] = 0.0;
         }
-        ++st.nlu;
+        // The factored iteration matrix is kept while c = h/alpha_k is unchanged (consecutive steps of equal size
+        // and order - the quasi-constant-step form makes that the common case).  It is rebuilt at the current
+        // predictor when c changed, or - by repeating this attempt - when Newton did not converge with the stale
+        // matrix (bdf.py:343-357, `current_jac`).
+        const bool fresh = !lu_valid || c != c_lu || force_rebuild;
+        if (fresh) {
+            ++st.nlu;
+            lu_valid = wave_build_and_factor(lane, yp, psi, p, c, B);
+            c_lu = c;
+            force_rebuild = false;
+        }
         bool converged = false;
         int n_iter = 0;
-        if (wave_build_and_factor(lane, yp, psi, p, c, B)) {
+        if (lu_valid) {
             double dy_norm_old = -1.0;
             
             for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
@@ -282,8 +294,13 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
                 dy_norm_old = dy_norm;
             }
         }
+        if (!converged && !fresh) {   // stale matrix: same step again with a fresh one
+            force_rebuild = true;
+            continue;
+        }
         if (!converged) {
             ++st.newton_fail;
+            lu_valid = false;
             h_abs *= 0.5;
             wave_change_D(D, order, 0.5, node);
             n_equal = 0;
