@@ -14,3 +14,4 @@ from .comm import RcclComm, SingleComm, TorchDistComm  # noqa: F401
 from .driver import SMCSettings, ess_candidates, ess_search, mvn_transform, proposal_cov, resample, run_smc, sample_prior  # noqa: F401
 from .engine import HipEngine  # noqa: F401
 from . import methanation  # noqa: F401
+from . import datagen  # noqa: F401

@@ -162,8 +162,24 @@ def mvn_transform(cov_m):
     return np.sqrt(sv)[:, None] * v
 
 
+def _dump(dump_dir, name, arr, rank, world, header=None):
+    """Per-step particle dumps in the reference's format (np.savetxt(..., delimiter=','),
+    SMC_methanation_main.py:181,422; methanation_functions.py:232-234).  With several ranks every rank writes its
+    own block (suffix _rank<r>); concatenating them in rank order gives the reference's file."""
+    import os
+    os.makedirs(os.path.join(dump_dir, "pred"), exist_ok=True)
+    suffix = "" if world == 1 else f"_rank{rank}"
+    path = os.path.join(dump_dir, name + suffix + ".csv")
+    if header is None:
+        np.savetxt(path, arr, delimiter=',')
+    else:
+        import pandas as pd
+        pd.DataFrame(arr, columns=header).to_csv(path, index=False)   # methanation_functions.py:231-232
+    return path
+
+
 def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy", verbose: bool = True,
-            p_pred0=None, seed_device: int | None = None, log=print):
+            p_pred0=None, seed_device: int | None = None, log=print, dump_dir: str | None = None):
     """Run the tempering loop (main:95-262).  The engine must already hold the model and the prior.
 
     Returns a dict: final particles (this rank's block), lk, schedule records, logZ, counters.
@@ -202,6 +218,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         stats["rk_attempts"] += info["rk_attempts"]
         stats["n_failed"] += info["n_failed"]
 
+    if dump_dir:
+        _dump(dump_dir, "pred/first_p_pred", engine.download_particles(SMC_SET_PRED), rank, world)
     info = engine.loglik(SMC_SET_PRED)                                        # main:98
     account(info)
     if int(comm.allreduce_sum_i64([info["n_failed"]])[0]):
@@ -274,9 +292,15 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         if gamma_new == 1.0:                                                  # :259
             break
         gamma_old = gamma_new
+        if dump_dir:                                                          # SMC_methanation_main.py:422
+            _dump(dump_dir, f"pred/{step}_p_pred", engine.download_particles(SMC_SET_PRED), rank, world)
     if gamma_new < 1.0 and verbose and rank == 0:
         log("tempering does't complete: last gamma =", gamma_new)             # :270-271
     engine.synchronize()
+    if dump_dir:                                                              # SavePosteriorcsv, :434-436
+        final = engine.download_particles(SMC_SET_PRED)
+        _dump(dump_dir, "pred/last_p_pred", final, rank, world)
+        _dump(dump_dir, "Posterior_Distribution", final, rank, world, header=list(s.priors.keys()))
     return {"p_pred": engine.download_particles(SMC_SET_PRED), "lk": engine.download_lk(SMC_SET_PRED),
             "records": records, "logZ": logZ, "gamma": gamma_new, "step": step, "stats": stats,
             "wall_s": time.perf_counter() - start_time}

@@ -553,3 +553,38 @@ def test_multi_rank_resample_exchange_exact(pkg, O, data):
     assert np.array_equal(np.concatenate([x[1] for x in res]), p_filt)
     assert np.array_equal(np.concatenate([x[2] for x in res]), lk1)
     assert p_is[:nl].sum() > 0.9 * n      # the exchange really moved particles across ranks
+
+
+# ---------------------------------------------------------------------------------------------------
+# "next" rows: per-step dumps (N3) and the pseudo-data generator (N4)
+# ---------------------------------------------------------------------------------------------------
+def test_per_step_dumps_match_reference_format(pkg, data, golden_run, tmp_path):
+    g = golden_run
+    with make_engine(pkg, data, 1000) as eng:
+        out = pkg.run_smc(eng, pkg.SMCSettings(), rng="numpy", verbose=False, dump_dir=str(tmp_path))
+    first = np.loadtxt(tmp_path / "pred" / "first_p_pred.csv", delimiter=",")
+    assert np.array_equal(first, g["sweeps_theta"][0])                     # the prior sample, full precision
+    steps = int(g["final_step"])
+    for k in range(1, steps):                                               # the terminating step is not dumped (:259-266)
+        assert (tmp_path / "pred" / f"{k}_p_pred.csv").exists()
+    assert not (tmp_path / "pred" / f"{steps}_p_pred.csv").exists()
+    last = np.loadtxt(tmp_path / "pred" / "last_p_pred.csv", delimiter=",")
+    assert np.array_equal(last, out["p_pred"]) and np.abs(last - g["final_p_pred"]).max() < 1e-9
+    import pandas as pd
+    post = pd.read_csv(tmp_path / "Posterior_Distribution.csv")
+    assert list(post.columns) == ["Vmax", "Km", "sigma"] and np.array_equal(post.values, last)
+    # a dump is a valid restart point
+    with make_engine(pkg, data, 1000) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, np.loadtxt(tmp_path / "pred" / "5_p_pred.csv", delimiter=","))
+        assert eng.loglik(pkg.SMC_SET_PRED)["n_failed"] == 0
+
+
+def test_pseudo_data_generator_reproduces_reference_csvs(pkg, data, tmp_path):
+    """The committed data files mm_pseudo_data_1..5 were produced by the reference's generator with seeds
+    20250205+i; the GPU generator reproduces them (same NumPy noise, P_true from the HIP RK45: <= 1e-9)."""
+    frames = pkg.datagen.make_pseudo_data(out_dir=str(tmp_path))
+    for i, df in enumerate(frames, start=1):
+        assert np.array_equal(df["t"].values, data.t[i])
+        assert np.abs(df["P_obs"].values - data.P_obs[i]).max() < 1e-9
+        assert df["S_true"].iloc[0] == data.S0[i]
+        assert (tmp_path / f"mm_pseudo_data_{i}.csv").exists()
