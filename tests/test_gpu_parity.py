@@ -571,7 +571,7 @@ def test_per_step_dumps_match_reference_format(pkg, data, golden_run, tmp_path):
     last = np.loadtxt(tmp_path / "pred" / "last_p_pred.csv", delimiter=",")
     assert np.array_equal(last, out["p_pred"]) and np.abs(last - g["final_p_pred"]).max() < 1e-9
     import pandas as pd
-    post = pd.read_csv(tmp_path / "Posterior_Distribution.csv")
+    post = pd.read_csv(tmp_path / "Posterior_Distribution.csv", float_precision="round_trip")
     assert list(post.columns) == ["Vmax", "Km", "sigma"] and np.array_equal(post.values, last)
     # a dump is a valid restart point
     with make_engine(pkg, data, 1000) as eng:
