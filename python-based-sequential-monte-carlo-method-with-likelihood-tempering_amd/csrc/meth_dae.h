@@ -61,7 +61,17 @@ struct Ws {
 struct DaeStats {
     int steps, rejects, newton_fail, nlu, newton_iters;
     int status;  // 0 ok, 1 step-size underflow / attempt budget exhausted, 2 singular block
+#ifdef SMC_METH_PROFILE
+    long long prof[8];  // shader-clock cycles: 0 build+factor, 1 residual, 2 forward, 3 backward, 4 total, 5 change_D, 6 predictor, 7 D update
+#endif
 };
+#ifdef SMC_METH_PROFILE
+#define SMC_PROF_BEGIN() long long prof_t0_ = clock64()
+#define SMC_PROF_ADD(st_, slot_) do { const long long prof_t1_ = clock64(); (st_).prof[slot_] += prof_t1_ - prof_t0_; prof_t0_ = prof_t1_; } while (0)
+#else
+#define SMC_PROF_BEGIN() do {} while (0)
+#define SMC_PROF_ADD(st_, slot_) do {} while (0)
+#endif
 
 namespace k {  // constants (methanation_set_conditon.py:74-89)
 constexpr double Dz = 0.95e-5, Rhos = 5075, Hr = -164940, R = 8.3144589, Cpg = 2800, Cps = 698, Keff = 0.72,

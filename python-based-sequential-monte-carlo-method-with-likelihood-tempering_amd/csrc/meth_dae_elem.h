@@ -1,0 +1,508 @@
+// meth_dae_elem.h -- K8 v3: one solve per wave; block elimination and the two substitution scans in ELEMENT layout.
+//
+// Measured on v2 (meth_dae_wave.h, cycle counters, tools/meth_dae_bench.py): 78 % of a solve is the three scans
+// over the 51 nodes (forward 35 %, factorisation 27 %, backward 16 %), and a scan step is ISSUE-bound: with
+// lane = node only ONE lane works on the 7x7 block of the current node, yet every wave64 FP64 instruction
+// occupies the SIMD for >= 4 cycles whatever the exec mask says (174 instructions = 886 cycles per forward step).
+//
+// v3 keeps lane = node for everything that is parallel over nodes (residuals, Jacobian blocks, predictor, norms)
+// and gives the scans a second layout: lane = 8 r + c holds ELEMENT (r, c) of the 7x7 block of EVERY node,
+//      X[i] = (D'_i)^{-1}[r][c]      G[i] = ((D'_i)^{-1} U_i)[r][c]      i = 0..50   (2 x 51 registers per lane)
+//   * a scan step is then one multiply, a 3-level butterfly over the 8 lanes that share a row, and one subtract:
+//         forward   z_i = X_i (b_i - L_i z_{i-1})      backward   x_i = z_i - G_i x_{i+1}
+//     (L_i has three non-zeros per row: diagonal, the u column, one T entry; its coefficients come from LDS);
+//   * consecutive nodes ALTERNATE between the layout above and its transpose, so the reduced vector lands exactly
+//     where the next step needs it: even nodes reduce over c with DPP (quad_perm, row_half_mirror), odd nodes over r
+//     with DPP row_ror:8 + v_permlane16_swap + v_permlane32_swap (gfx950).  No transposition on the chain;
+//   * the factorisation is a Gauss-Jordan inversion of D'_i = D_i - L_i G_{i-1} spread over the 49 lanes (pivot
+//     row / column by ds_bpermute, reciprocal pivot wave-uniform); rows 5/6 are already swapped by node_eval so
+//     that no pivoting is needed (meth_dae.h).  The inverse is explicit because the iteration matrix of a modified
+//     Newton method only steers convergence: the converged step does not depend on it;
+//   * node-layout results reach the element layout through a 2.8 KB LDS staging row (Jacobian rows, right-hand
+//     sides) and come back the same way.
+// LDS per wave: differences array 8 x 7 x 51, L/U coefficients 51 x 24, staging 2 x 357 doubles = 38.4 KB, so four
+// waves (one per SIMD) still share a CU.  Time stepping, Newton control and error tests are those of meth_dae.h.
+// PARITY UNPINNED against the reference's IDA (see meth_dae.h); checked against v2, the CPU build and the CPU checker.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "meth_dae.h"
+#include "meth_dae_wave.h"
+
+namespace smc {
+namespace meth {
+
+constexpr int kLdsD = 0;                         // D[k][f][node], k < 8
+constexpr int kLdsCf = kLdsD + 8 * 7 * kNX;      // per node 24: Ld[0..6],0 | Lx[0..6],0 | Ud[0..5],0,U65
+constexpr int kLdsB = kLdsCf + kNX * 24;         // b[node][7]  (also the staging row of the Jacobian transposition)
+constexpr int kLdsZ = kLdsB + kNX * 7;           // z / x [node][7]
+constexpr int kLdsDoubles = kLdsZ + kNX * 7;     // 4794 doubles = 38352 bytes
+
+struct DViewE {   // differences array, node-major within a row (only lanes < kNX may touch it)
+    double *s;
+    int lane;
+    __device__ __forceinline__ double &operator()(int k, int f) const { return s[(k * 7 + f) * kNX + lane]; }
+};
+
+__device__ __forceinline__ void wave_lds_sync() {   // one wave per workgroup: LDS operations complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over lane bits 0..2 (the 8 lanes of a group)
+__device__ __forceinline__ double allsum_group8(double v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    return v;
+}
+// all-reduce over lane bits 3..5 (same position in the 8 groups)
+__device__ __forceinline__ double allsum_across8(double v) {
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v;
+}
+template <int Q>
+__device__ __forceinline__ double allsum_over_mc(double v) {   // Q = node parity: the column index is c (0) or r (1)
+    if (Q == 0) return allsum_group8(v);
+    return allsum_across8(v);
+}
+
+struct ElemLane {   // lane = 8 r + c
+    int r, c, lane;
+    __device__ __forceinline__ explicit ElemLane(int l) : r(l >> 3), c(l & 7), lane(l) {}
+    template <int Q> __device__ __forceinline__ int mr() const { return Q ? c : r; }   // block row held for parity Q
+    template <int Q> __device__ __forceinline__ int mc() const { return Q ? r : c; }   // block column
+};
+__device__ __forceinline__ int min6(int v) { return v < 6 ? v : 6; }
+
+// reciprocal of a wave-uniform value: v_rcp_f64 (2^-24) + two Newton steps
+__device__ __forceinline__ double recip2(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-a, x, 1.0);
+    return fma(x, e, x);
+}
+
+// one node of the block elimination; Q = I & 1
+template <int I>
+__device__ __forceinline__ bool elem_factor_node(const ElemLane &L, const double *cf, double (&X)[kNX], double (&G)[kNX]) {
+    constexpr int Q = I & 1;
+    const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
+    const double *cfi = cf + I * 24;
+    double a = X[I];
+    if (I > 0) {
+        constexpr int IP = (I > 0) ? I - 1 : 0;
+        const int kap = mr < 6 ? 6 : 5;
+        const int srcK = Q ? (kap * 8 + L.r) : (L.c * 8 + kap);   // holder of G_{I-1}[kap][mc] (parity 1-Q)
+        const double gT = __shfl(G[IP], L.c * 8 + L.r);            // G_{I-1}[mr][mc]
+        const double gK = __shfl(G[IP], srcK);
+        const double ld = cfi[min6(mr)], lx = cfi[8 + min6(mr)];
+        a = fma(-lx, gK, fma(-ld, gT, a));
+    }
+    int ok = 1;
+    const double rowsign = Q ? -1.0 : 1.0;
+#pragma unroll 1
+    for (int kk = 0; kk < 7; ++kk) {
+        const double akk = lane_bcast(a, 9 * kk);
+        if (!(fabs(akk) > 1e-300) || !(fabs(akk) < 1e300)) ok = 0;
+        const double p = recip2(akk);
+        const double u = __shfl(a, (L.lane & ~7) | kk);   // lane (r, k)
+        const double v = __shfl(a, kk * 8 + L.c);         // lane (k, c)
+        const double gen = fma(-(u * v), p, a);
+        const double ap = a * p * rowsign;
+        const bool rk = L.r == kk, ck = L.c == kk;
+        a = rk ? (ck ? p : ap) : (ck ? -ap : gen);
+    }
+    X[I] = a;
+    {
+        const int src6 = Q ? (48 + L.c) : ((L.lane & ~7) | 6);   // holder of X_I[mr][6]
+        const double tU = __shfl(a, src6);
+        const double ud = cfi[16 + min6(mc)], u65 = cfi[23];
+        G[I] = fma(a, ud, (mc == 5) ? tU * u65 : 0.0);
+    }
+    return ok != 0;
+}
+
+template <int I>
+struct ElemFactorLoop {
+    static __device__ __forceinline__ bool run(const ElemLane &L, const double *cf, double (&X)[kNX], double (&G)[kNX]) {
+        const bool below = ElemFactorLoop<I - 1>::run(L, cf, X, G);
+        return elem_factor_node<I>(L, cf, X, G) && below;
+    }
+};
+template <>
+struct ElemFactorLoop<-1> {
+    static __device__ __forceinline__ bool run(const ElemLane &, const double *, double (&)[kNX], double (&)[kNX]) { return true; }
+};
+
+// iteration matrix at the predictor (parallel over nodes), transposition into the element layout, block elimination
+__device__ __forceinline__ bool elem_build_and_factor(int lane, double *lds, const double *yp, const double *psi,
+                                                      const double *p, double c, double (&X)[kNX], double (&G)[kNX]) {
+    const double cj = 1.0 / c;
+    const bool node = lane < kNX;
+    const ElemLane L(lane);
+    double *cf = lds + kLdsCf, *stage = lds + kLdsB;
+    {
+        double wm[7], wp[7], yd0[7], res[7], Lb[kNB], Db[kNB], Ub[kNB];
+        neighbours(yp, wm, wp);
+        SMC_UNROLL
+        for (int f = 0; f < 7; ++f) yd0[f] = psi[f] * cj;
+        SMC_UNROLL
+        for (int q = 0; q < kNB; ++q) Lb[q] = Db[q] = Ub[q] = 0.0;
+        if (node) node_eval<true>(lane, wm, yp, wp, yd0, p, cj, res, Lb, Db, Ub);
+        SMC_UNROLL
+        for (int i = 0; i < kNX; ++i) X[i] = 0.0;
+        if (node) {
+            double *o = cf + lane * 24;
+            SMC_UNROLL
+            for (int r = 0; r < 7; ++r) {
+                o[r] = Lb[r * 7 + r];
+                o[8 + r] = (r < 6) ? Lb[r * 7 + 6] : Lb[6 * 7 + 5];
+                o[16 + r] = (r < 6) ? Ub[r * 7 + r] : 0.0;
+            }
+            o[7] = 0.0;
+            o[15] = 0.0;
+            o[23] = Ub[6 * 7 + 5];
+        }
+        SMC_UNROLL
+        for (int rho = 0; rho < 7; ++rho) {   // one block row of all nodes per pass through the staging row
+            if (node)
+                SMC_UNROLL
+                for (int cc = 0; cc < 7; ++cc) stage[lane * 7 + cc] = Db[rho * 7 + cc];
+            wave_lds_sync();
+            if (L.r == rho && L.c < 7)        // even nodes: lane (r, c) holds [r][c]
+                SMC_UNROLL
+                for (int i = 0; i < kNX; i += 2) X[i] = stage[i * 7 + L.c];
+            if (L.c == rho && L.r < 7)        // odd nodes: lane (r, c) holds [c][r]
+                SMC_UNROLL
+                for (int i = 1; i < kNX; i += 2) X[i] = stage[i * 7 + L.r];
+            wave_lds_sync();
+        }
+    }
+    const bool ok = ElemFactorLoop<kNX - 1>::run(L, cf, X, G);
+    return __all(ok);
+}
+
+template <int I>
+struct ElemForward {   // z_I = X_I (b_I - L_I z_{I-1}); returns z_I[mr] on every lane
+    static __device__ __forceinline__ double run(const ElemLane &L, const double *cf, const double *b, double *z,
+                                                 const double (&X)[kNX]) {
+        constexpr int Q = I & 1;
+        const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
+        double t = b[I * 7 + min6(mc)];
+        if (I > 0) {
+            const double zprev = ElemForward<I - 1>::run(L, cf, b, z, X);   // z_{I-1}[mc]
+            const double z6 = lane_bcast(zprev, Q ? 48 : 6), z5 = lane_bcast(zprev, Q ? 40 : 5);
+            const double zx = (mc == 6) ? z5 : z6;
+            const double *cfi = cf + I * 24;
+            t = fma(-cfi[8 + min6(mc)], zx, fma(-cfi[min6(mc)], zprev, t));
+        }
+        const double zi = allsum_over_mc<Q>(X[I] * t);
+        if (mc == 0 && mr < 7) z[I * 7 + mr] = zi;
+        return zi;
+    }
+};
+template <>
+struct ElemForward<-1> {
+    static __device__ __forceinline__ double run(const ElemLane &, const double *, const double *, double *,
+                                                 const double (&)[kNX]) { return 0.0; }
+};
+
+template <int I>
+struct ElemBackward {   // x_I = z_I - G_I x_{I+1}, I = 49 .. 0; `xnext` is x_{I+1}[mc]
+    static __device__ __forceinline__ void run(const ElemLane &L, double *z, const double (&G)[kNX], double xnext) {
+        constexpr int Q = I & 1;
+        const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
+        const double zi = z[I * 7 + min6(mr)];
+        const double xi = zi - allsum_over_mc<Q>(G[I] * xnext);
+        if (mc == 0 && mr < 7) z[I * 7 + mr] = xi;
+        ElemBackward<I - 1>::run(L, z, G, xi);
+    }
+};
+template <>
+struct ElemBackward<-1> {
+    static __device__ __forceinline__ void run(const ElemLane &, double *, const double (&)[kNX], double) {}
+};
+
+// one modified-Newton iteration; returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
+__device__ __forceinline__ double elem_newton_iteration(int lane, double *lds, double *y, double *dd, const double *yp,
+                                                        const double *psi, const double *p, double c, double rtol,
+                                                        double atol, const double (&X)[kNX], const double (&G)[kNX],
+                                                        DaeStats &st) {
+    SMC_PROF_BEGIN();
+    const double cj = 1.0 / c;
+    const bool node = lane < kNX;
+    const ElemLane L(lane);
+    double *b = lds + kLdsB, *z = lds + kLdsZ;
+    const double *cf = lds + kLdsCf;
+    int finite = 1;
+    {
+        double wm[7], wp[7], yd0[7], res[7];
+        neighbours(y, wm, wp);
+        SMC_UNROLL
+        for (int f = 0; f < 7; ++f) yd0[f] = (psi[f] + dd[f]) * cj;
+        if (node) {
+            node_eval<false>(lane, wm, y, wp, yd0, p, cj, res, nullptr, nullptr, nullptr);
+            SMC_UNROLL
+            for (int r = 0; r < 7; ++r) {
+                if (!(res[r] - res[r] == 0.0)) finite = 0;
+                b[lane * 7 + r] = -res[r];
+            }
+        }
+    }
+    if (!__all(finite)) return -1.0;
+    wave_lds_sync();
+    SMC_PROF_ADD(st, 1);
+    const double zlast = ElemForward<kNX - 1>::run(L, cf, b, z, X);
+    SMC_PROF_ADD(st, 2);
+    ElemBackward<kNX - 2>::run(L, z, G, zlast);
+    wave_lds_sync();
+    SMC_PROF_ADD(st, 3);
+    double sumsq = 0.0;
+    if (node)
+        SMC_UNROLL
+        for (int f = 0; f < 7; ++f) {
+            const double dx = z[lane * 7 + f];
+            const double sc = atol + rtol * fabs(yp[f]);
+            const double q = dx / sc;
+            sumsq += q * q;
+            y[f] += dx;
+            dd[f] += dx;
+        }
+    wave_lds_sync();
+    return sqrt(wave_allsum(sumsq) / kNS);
+}
+
+// bdf.py compute_R / change_D with static loops (no scratch): D[0..order] <- (R(factor) U)^T D[0..order].
+// U = R(1) is upper triangular, so the 6 x 6 product does not depend on the order; rows above it are masked.
+__device__ __forceinline__ void elem_change_D(const DViewE &D, int order, double factor, bool node) {
+    double R[6][6], RU[6][6];
+    SMC_UNROLL
+    for (int j = 0; j < 6; ++j) R[0][j] = 1.0;
+    SMC_UNROLL
+    for (int i = 1; i < 6; ++i) {
+        R[i][0] = 0.0;
+        SMC_UNROLL
+        for (int j = 1; j < 6; ++j) R[i][j] = R[i - 1][j] * ((i - 1 - factor * j) * (1.0 / i));
+    }
+    SMC_UNROLL
+    for (int i = 0; i < 6; ++i)
+        SMC_UNROLL
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            SMC_UNROLL
+            for (int q = 0; q <= j; ++q) {
+                double u = (q == 0) ? 1.0 : 0.0;   // U[q][j] = prod_{m=1..q} (m-1-j)/m for j >= 1; U[q][0] = delta_q0
+                if (j >= 1) {
+                    u = 1.0;
+                    SMC_UNROLL
+                    for (int m = 1; m <= q; ++m) u *= (double)(m - 1 - j) / (double)m;
+                }
+                s += R[i][q] * u;
+            }
+            RU[i][j] = (i <= order) ? s : 0.0;
+        }
+    if (!node) return;
+    SMC_UNROLL
+    for (int f = 0; f < 7; ++f) {
+        double dcol[6];
+        SMC_UNROLL
+        for (int i = 0; i < 6; ++i) dcol[i] = D(i, f);
+        SMC_UNROLL
+        for (int j = 0; j < 6; ++j) {
+            double s = 0.0;
+            SMC_UNROLL
+            for (int i = 0; i < 6; ++i) s += RU[i][j] * dcol[i];
+            if (j <= order) D(j, f) = s;
+        }
+    }
+}
+
+// Integrate one solve (the whole wave cooperates).  lds: this wave's region of kLdsDoubles doubles, holding y0 in
+// row 0 of the differences array and zeros in rows 1..7 on entry; the state at tf is left in row 0.
+__device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const double *p, double tf, double rtol,
+                                                   double atol, double h0, int max_attempts, DaeStats &st) {
+    const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+    const bool node = lane < kNX;
+    const DViewE D{lds + kLdsD, lane};
+    st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
+    st.status = 0;
+#ifdef SMC_METH_PROFILE
+    for (int q = 0; q < 8; ++q) st.prof[q] = 0;
+    const long long prof_start_ = clock64();
+#endif
+    double t = 0.0, h_abs = h0;
+    int order = 1, n_equal = 0, attempts = 0;
+    double X[kNX], G[kNX];
+    bool lu_valid = false, force_rebuild = false;
+    double c_lu = 0.0;
+    double yp[7], y[7], psi[7], dd[7];
+    while (t < tf) {  // one iteration = one step attempt (all quantities below are wave-uniform)
+        if (h_abs < 1e-14 * fmax(1.0, t) || attempts >= max_attempts) { st.status = 1; break; }
+        ++attempts;
+        double t_new = t + h_abs;
+        if (t_new - tf > 0) {
+            t_new = tf;
+            { SMC_PROF_BEGIN(); elem_change_D(D, order, fabs(t_new - t) / h_abs, node); SMC_PROF_ADD(st, 5); }
+            n_equal = 0;
+        }
+        const double h = t_new - t;
+        h_abs = fabs(h);
+        const double c = h / bdf_alpha(order);
+        SMC_PROF_BEGIN();
+        {
+            double s[7], q[7];
+            SMC_UNROLL
+            for (int f = 0; f < 7; ++f) s[f] = q[f] = 0.0;
+            if (node) {
+                SMC_UNROLL
+                for (int kk = 0; kk <= kMaxOrder; ++kk)
+                    if (kk <= order)
+                        SMC_UNROLL
+                        for (int f = 0; f < 7; ++f) {
+                            const double dv = D(kk, f);
+                            s[f] += dv;
+                            if (kk >= 1) q[f] += dv * bdf_gamma(kk);
+                        }
+            }
+            const double inv_alpha = 1.0 / bdf_alpha(order);
+            SMC_UNROLL
+            for (int f = 0; f < 7; ++f) {
+                yp[f] = y[f] = s[f];
+                psi[f] = q[f] * inv_alpha;
+                dd[f] = 0.0;
+            }
+        }
+        // The factored iteration matrix is kept while c = h/alpha_k is unchanged; rebuilt at the current predictor when
+        // c changed, or - by repeating this attempt - when Newton stalled on a stale matrix (bdf.py:343-357).
+        const bool fresh = !lu_valid || c != c_lu || force_rebuild;
+        SMC_PROF_ADD(st, 6);
+        if (fresh) {
+            ++st.nlu;
+            lu_valid = elem_build_and_factor(lane, lds, yp, psi, p, c, X, G);
+            SMC_PROF_ADD(st, 0);
+            c_lu = c;
+            force_rebuild = false;
+        }
+        bool converged = false;
+        int n_iter = 0;
+        if (lu_valid) {
+            double dy_norm_old = -1.0;
+#pragma unroll 1
+            for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
+                const double dy_norm = elem_newton_iteration(lane, lds, y, dd, yp, psi, p, c, rtol, atol, X, G, st);
+                n_iter = kk + 1;
+                ++st.newton_iters;
+                if (dy_norm < 0) break;
+                const double rate = (dy_norm_old >= 0) ? dy_norm / dy_norm_old : -1.0;
+                if (rate >= 0 && (rate >= 1 || pow(rate, kNewtonMaxIter - kk) / (1 - rate) * dy_norm > newton_tol)) break;
+                if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = true; break; }
+                dy_norm_old = dy_norm;
+            }
+        }
+        if (!converged && !fresh) {   // stale matrix: same step again with a fresh one
+            force_rebuild = true;
+            continue;
+        }
+        if (!converged) {
+            ++st.newton_fail;
+            lu_valid = false;
+            h_abs *= 0.5;
+            { SMC_PROF_BEGIN(); elem_change_D(D, order, 0.5, node); SMC_PROF_ADD(st, 5); }
+            n_equal = 0;
+            continue;
+        }
+        const double safety = 0.9 * (2 * kNewtonMaxIter + 1) / (2.0 * kNewtonMaxIter + n_iter);
+        double se = 0.0;
+        if (node)
+            SMC_UNROLL
+            for (int f = 0; f < 6; ++f) {
+                const double sc = atol + rtol * fabs(y[f]);
+                const double e = bdf_error_const(order) * dd[f] / sc;
+                se += e * e;
+            }
+        const double error_norm = sqrt(wave_allsum(se) / (6 * kNX));
+        if (!(error_norm <= 1)) {
+            ++st.rejects;
+            const double factor = (error_norm == error_norm) ? fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1))) : 0.2;
+            h_abs *= factor;
+            { SMC_PROF_BEGIN(); elem_change_D(D, order, factor, node); SMC_PROF_ADD(st, 5); }
+            n_equal = 0;
+            continue;
+        }
+        ++n_equal;
+        t = t_new;
+        ++st.steps;
+        const bool select = n_equal >= order + 1;
+        SMC_PROF_ADD(st, 7);   // Newton control + error test (everything since the factorisation)
+        double sm = 0.0, sp = 0.0;
+        if (node) {
+            double acc[7], d_order[7], dnew2[7];
+            SMC_UNROLL
+            for (int f = 0; f < 7; ++f) {
+                dnew2[f] = dd[f] - D(order + 1, f);
+                D(order + 2, f) = dnew2[f];
+                D(order + 1, f) = dd[f];
+                acc[f] = dd[f];
+                d_order[f] = 0.0;
+            }
+            SMC_UNROLL
+            for (int kk = kMaxOrder; kk >= 0; --kk)
+                if (kk <= order)
+                    SMC_UNROLL
+                    for (int f = 0; f < 7; ++f) {
+                        acc[f] += D(kk, f);
+                        D(kk, f) = acc[f];
+                        if (kk == order) d_order[f] = acc[f];
+                    }
+            if (select)
+                SMC_UNROLL
+                for (int f = 0; f < 6; ++f) {
+                    const double sc = atol + rtol * fabs(y[f]);
+                    if (order > 1) { const double e = bdf_error_const(order - 1) * d_order[f] / sc; sm += e * e; }
+                    if (order < kMaxOrder) { const double e = bdf_error_const(order + 1) * dnew2[f] / sc; sp += e * e; }
+                }
+        }
+        SMC_PROF_ADD(st, 6);   // D update shares the predictor slot
+        if (!select) continue;
+        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        const double em = (order > 1) ? sqrt(wave_allsum(sm) / (6 * kNX)) : inf;
+        const double ep = (order < kMaxOrder) ? sqrt(wave_allsum(sp) / (6 * kNX)) : inf;
+        const double fm = pow(em, -1.0 / order), f0 = pow(error_norm, -1.0 / (order + 1)), fp = pow(ep, -1.0 / (order + 2));
+        double best = fm;
+        int delta = -1;
+        if (f0 > best) { best = f0; delta = 0; }
+        if (fp > best) { best = fp; delta = 1; }
+        order += delta;
+        const double factor = fmin(10.0, safety * best);
+        h_abs *= factor;
+        { SMC_PROF_BEGIN(); elem_change_D(D, order, factor, node); SMC_PROF_ADD(st, 5); }
+        n_equal = 0;
+    }
+#ifdef SMC_METH_PROFILE
+    st.prof[4] = clock64() - prof_start_;
+#endif
+}
+
+}  // namespace meth
+}  // namespace smc

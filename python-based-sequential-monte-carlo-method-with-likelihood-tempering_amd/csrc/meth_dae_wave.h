@@ -160,7 +160,8 @@ __device__ __forceinline__ bool wave_build_and_factor(int lane, const double *yp
 // one modified-Newton iteration; returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
 __device__ __forceinline__ double wave_newton_iteration(int lane, double *y, double *dd, const double *yp,
                                                         const double *psi, const double *p, double c, double rtol,
-                                                        double atol, const WaveBlocks &B) {
+                                                        double atol, const WaveBlocks &B, DaeStats &st) {
+    SMC_PROF_BEGIN();
     const double cj = 1.0 / c;
     const bool node = lane < kNX;
     double wm[7], wp[7], yd0[7], b[7];
@@ -180,6 +181,7 @@ __device__ __forceinline__ double wave_newton_iteration(int lane, double *y, dou
         }
     }
     if (!__all(finite)) return -1.0;
+    SMC_PROF_ADD(st, 1);
     // forward: z_i = LU_i^{-1} (b_i - L_i z_{i-1})
     double z[7];
     SMC_UNROLL
@@ -200,6 +202,7 @@ __device__ __forceinline__ double wave_newton_iteration(int lane, double *y, dou
             for (int f = 0; f < 7; ++f) z[f] = b[f];
         }
     }
+    SMC_PROF_ADD(st, 2);
     // backward: x_i = z_i - G_i x_{i+1}
     for (int i = kNX - 2; i >= 0; --i) {
         double xn[6];
@@ -214,6 +217,7 @@ __device__ __forceinline__ double wave_newton_iteration(int lane, double *y, dou
                 z[r] = s;
             }
     }
+    SMC_PROF_ADD(st, 3);
     double sumsq = 0.0;
     if (node)
         SMC_UNROLL
@@ -236,6 +240,10 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
     const DView D{sD, lane};
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
     st.status = 0;
+#ifdef SMC_METH_PROFILE
+    for (int q = 0; q < 8; ++q) st.prof[q] = 0;
+    const long long prof_start_ = clock64();
+#endif
     double t = 0.0, h_abs = h0;
     int order = 1, n_equal = 0, attempts = 0;
     WaveBlocks B;
@@ -248,12 +256,13 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
         double t_new = t + h_abs;
         if (t_new - tf > 0) {
             t_new = tf;
-            wave_change_D(D, order, fabs(t_new - t) / h_abs, node);
+            { SMC_PROF_BEGIN(); wave_change_D(D, order, fabs(t_new - t) / h_abs, node); SMC_PROF_ADD(st, 5); }
             n_equal = 0;
         }
         const double h = t_new - t;
         h_abs = fabs(h);
         const double c = h / bdf_alpha(order);
+        SMC_PROF_BEGIN();
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) {
             double s = 0.0, q = 0.0;
@@ -272,9 +281,11 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
         // predictor when c changed, or - by repeating this attempt - when Newton did not converge with the stale
         // matrix (bdf.py:343-357, `current_jac`).
         const bool fresh = !lu_valid || c != c_lu || force_rebuild;
+        SMC_PROF_ADD(st, 6);
         if (fresh) {
             ++st.nlu;
             lu_valid = wave_build_and_factor(lane, yp, psi, p, c, B);
+            SMC_PROF_ADD(st, 0);
             c_lu = c;
             force_rebuild = false;
         }
@@ -284,7 +295,7 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
             double dy_norm_old = -1.0;
             
             for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
-                const double dy_norm = wave_newton_iteration(lane, y, dd, yp, psi, p, c, rtol, atol, B);
+                const double dy_norm = wave_newton_iteration(lane, y, dd, yp, psi, p, c, rtol, atol, B, st);
                 n_iter = kk + 1;
                 ++st.newton_iters;
                 if (dy_norm < 0) break;
@@ -302,7 +313,7 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
             ++st.newton_fail;
             lu_valid = false;
             h_abs *= 0.5;
-            wave_change_D(D, order, 0.5, node);
+            { SMC_PROF_BEGIN(); wave_change_D(D, order, 0.5, node); SMC_PROF_ADD(st, 5); }
             n_equal = 0;
             continue;
         }
@@ -320,7 +331,7 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
             ++st.rejects;
             const double factor = (error_norm == error_norm) ? fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1))) : 0.2;
             h_abs *= factor;
-            wave_change_D(D, order, factor, node);
+            { SMC_PROF_BEGIN(); wave_change_D(D, order, factor, node); SMC_PROF_ADD(st, 5); }
             n_equal = 0;
             continue;
         }
@@ -328,6 +339,7 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
         t = t_new;
         ++st.steps;
         const bool select = n_equal >= order + 1;
+        SMC_PROF_ADD(st, 7);   // Newton control + error test (everything since the factorisation)
         double sm = 0.0, sp = 0.0;
         if (node)
             SMC_UNROLL
@@ -349,6 +361,7 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
                     if (order < kMaxOrder) { const double e = bdf_error_const(order + 1) * dnew2 / sc; sp += e * e; }
                 }
             }
+        SMC_PROF_ADD(st, 6);   // D update shares the predictor slot
         if (!select) continue;
         const double inf = __longlong_as_double(0x7ff0000000000000LL);
         const double em = (order > 1) ? sqrt(wave_allsum(sm) / (6 * kNX)) : inf;
@@ -361,9 +374,12 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
         order += delta;
         const double factor = fmin(10.0, safety * best);
         h_abs *= factor;
-        wave_change_D(D, order, factor, node);
+        { SMC_PROF_BEGIN(); wave_change_D(D, order, factor, node); SMC_PROF_ADD(st, 5); }
         n_equal = 0;
     }
+#ifdef SMC_METH_PROFILE
+    st.prof[4] = clock64() - prof_start_;
+#endif
 }
 
 }  // namespace meth

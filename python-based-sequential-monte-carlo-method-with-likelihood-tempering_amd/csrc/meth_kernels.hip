@@ -10,6 +10,7 @@
 #include "../../include/smc_hip.h"
 #include "meth_dae.h"
 #include "meth_dae_wave.h"
+#include "meth_dae_elem.h"
 #include "meth_model.h"
 
 namespace smc {
@@ -132,6 +133,58 @@ dae_wave_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
             atomicAdd(&counters[1], (unsigned long long)st.rejects);
             atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
+#ifdef SMC_METH_PROFILE
+            atomicAdd(&counters[4], (unsigned long long)st.nlu);
+            for (int q = 0; q < 8; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
+#endif
+        }
+        if (y_final && lane < kNX)
+            for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + lane] = D(0, f);
+    }
+}
+
+// K8 v3: one wave per solve, scans in element layout (meth_dae_elem.h); solves are handed out by an atomic counter
+// (a failed solve runs its whole attempt budget, ~9x an ordinary one, so a static split leaves waves idle).
+__global__ void __launch_bounds__(64)
+dae_elem_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0_all, int64_t n_solves, double tf,
+                double rtol, double atol, double h0, int max_attempts, double S, double P_stp,
+                double *__restrict__ flows, double *__restrict__ y_final, int *__restrict__ status,
+                unsigned long long *__restrict__ counters) {
+    extern __shared__ double lds[];  // kLdsDoubles
+    const int lane = threadIdx.x;
+    const DViewE D{lds + kLdsD, lane};
+    for (;;) {
+        unsigned long long nxt = 0;
+        if (lane == 0) nxt = atomicAdd(&counters[5], 1ULL);
+        const int64_t sidx = (int64_t)__shfl(nxt, 0);
+        if (sidx >= n_solves) break;
+        double p[18];
+        for (int q = 0; q < 18; ++q) p[q] = p0_all[sidx * 18 + q];
+        if (lane < kNX)
+            for (int f = 0; f < 7; ++f) {
+                D(0, f) = y0_all[sidx * kNS + f * kNX + lane];
+                for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
+            }
+        DaeStats st;
+        dae_elem_integrate(lds, lane, p, tf, rtol, atol, h0, max_attempts, st);
+        if (lane == kNX - 1) {
+            const double u = D(0, 6), T = D(0, 5);
+            const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
+            for (int f = 0; f < 5; ++f) {
+                const double cc = D(0, f);
+                flows[sidx * 5 + f] = (st.status == 0)
+                                          ? cc * S * u * 60 * k::R * T / (P_total) * 1e6 * (P_total) / P_stp * 298 / T
+                                          : -10000.0;
+            }
+            status[sidx] = st.status;
+            atomicAdd(&counters[0], (unsigned long long)st.steps);
+            atomicAdd(&counters[1], (unsigned long long)st.rejects);
+            atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
+            atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
+#ifdef SMC_METH_PROFILE
+            atomicAdd(&counters[4], (unsigned long long)st.nlu);
+            for (int q = 0; q < 8; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
+#endif
         }
         if (y_final && lane < kNX)
             for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + lane] = D(0, f);
@@ -229,6 +282,7 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     hipDeviceProp_t prop;
     MH(hipGetDeviceProperties(&prop, device));
     const bool v1 = getenv("SMC_METH_DAE_V1") != nullptr;   // debug: the thread-per-solve version (meth_dae.h)
+    const bool v2 = getenv("SMC_METH_DAE_V2") != nullptr;   // debug: lane = node scans (meth_dae_wave.h)
     int64_t nslots = ((n_solves + 63) / 64) * 64;
     const int64_t max_slots = (int64_t)prop.multiProcessorCount * 256;   // 4 waves per CU
     if (nslots > max_slots) nslots = max_slots;
@@ -240,11 +294,11 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipMalloc(&dy0, (size_t)n_solves * kNS * 8)); bufs.push_back(dy0);
     MH(hipMalloc(&dfl, (size_t)n_solves * 5 * 8)); bufs.push_back(dfl);
     MH(hipMalloc(&dst, (size_t)n_solves * sizeof(int))); bufs.push_back(dst);
-    MH(hipMalloc(&dcnt, 4 * sizeof(unsigned long long))); bufs.push_back(dcnt);
+    MH(hipMalloc(&dcnt, 16 * sizeof(unsigned long long))); bufs.push_back(dcnt);
     if (y_final) { MH(hipMalloc(&dyf, (size_t)n_solves * kNS * 8)); bufs.push_back(dyf); }
     MH(hipMemcpy(dp, p0_all, (size_t)n_solves * 18 * 8, hipMemcpyHostToDevice));
     MH(hipMemcpy(dy0, y0_all, (size_t)n_solves * kNS * 8, hipMemcpyHostToDevice));
-    MH(hipMemset(dcnt, 0, 4 * sizeof(unsigned long long)));
+    MH(hipMemset(dcnt, 0, 16 * sizeof(unsigned long long)));
     hipEvent_t e0, e1;
     MH(hipEventCreate(&e0));
     MH(hipEventCreate(&e1));
@@ -252,6 +306,11 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     if (v1) {
         hipLaunchKernelGGL(dae_kernel, dim3((unsigned)(nslots / 64)), dim3(64), 0, 0, dws, nslots, dp, dy0, n_solves, tf,
                            rtol, atol, h0, 3000, S, P_stp, dfl, dyf, dst, dcnt);
+    } else if (!v2) {
+        int64_t nwaves = (int64_t)prop.multiProcessorCount * 4;
+        if (nwaves > n_solves) nwaves = n_solves;
+        hipLaunchKernelGGL(dae_elem_kernel, dim3((unsigned)nwaves), dim3(64), kLdsDoubles * sizeof(double), 0, dp, dy0,
+                           n_solves, tf, rtol, atol, h0, 3000, S, P_stp, dfl, dyf, dst, dcnt);
     } else {
         int64_t nwaves = (int64_t)prop.multiProcessorCount * 4;
         if (nwaves > n_solves) nwaves = n_solves;
@@ -274,6 +333,20 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
         MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
         for (int q = 0; q < 4; ++q) stats[q] = (int64_t)h[q];
     }
+#ifdef SMC_METH_PROFILE
+    {
+        unsigned long long h[16];
+        MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
+        static const char *nm[8] = {"build+factor", "residual", "forward", "backward", "total", "change_D", "predict+Dupd", "newton+errtest"};
+        fprintf(stderr, "[meth profile] solves %lld  nlu/solve %.1f  newton/solve %.1f  steps/solve %.1f\n", (long long)n_solves,
+                (double)h[4] / n_solves, (double)h[3] / n_solves, (double)h[0] / n_solves);
+        for (int q = 0; q < 8; ++q)
+            fprintf(stderr, "[meth profile] %-14s %10.0f cycles/solve  (%.1f %% of total)\n", nm[q], (double)h[8 + q] / n_solves,
+                    100.0 * h[8 + q] / (double)h[12]);
+        fprintf(stderr, "[meth profile] per factorisation %.0f cycles; per newton iteration: residual %.0f forward %.0f backward %.0f\n",
+                (double)h[8] / h[4], (double)h[9] / h[3], (double)h[10] / h[3], (double)h[11] / h[3]);
+    }
+#endif
     for (void *q : bufs) (void)hipFree(q);
     return 0;
 }

@@ -191,6 +191,7 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_blk_r);
     (void)hipFree(c->d_blk_c);
     (void)hipFree(c->d_sendbuf);
+    (void)hipFree(c->d_recvbuf);
     (void)hipFree(c->dbg_lk2);
     (void)hipFree(c->dbg_r);
     (void)hipFree(c->d_sum_r2);
@@ -625,26 +626,50 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
         HIPC(c, hipStreamSynchronize(c->stream));
         return 0;
     }
-    // 3. exchange: per peer and component one send / one recv, received straight into the SoA rows
+    // 3. exchange: ONE contiguous send and ONE contiguous recv per peer ([component][cnt] blocks), then the
+    //    received blocks are spread over the SoA rows by device-to-device row copies on the same stream
     if (W > 1) {
         ncclComm_t comm = (ncclComm_t)c->nccl_comm;
+        std::vector<int64_t> recv_off(W, 0), recv_cnt(W, 0), recv_row(W, 0);
+        int64_t roff = 0;
+        for (int q = 0; q < W; ++q) {
+            if (q == R) continue;
+            const int64_t lo = imax(out_base_all[q], R * nl), hi = imin(out_base_all[q] + offspring_all[q], (R + 1) * nl);
+            if (hi <= lo) continue;
+            recv_off[q] = roff;
+            recv_cnt[q] = hi - lo;
+            recv_row[q] = lo - R * nl;
+            roff += hi - lo;
+        }
+        if (roff > c->recvbuf_cap) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_recvbuf);
+            c->d_recvbuf = nullptr;
+            c->recvbuf_cap = 0;
+            HIPC(c, hipMalloc(&c->d_recvbuf, (size_t)roff * (d + 1) * sizeof(double)));
+            c->recvbuf_cap = roff;
+        }
         NCCLC(c, ncclGroupStart());
         for (int q = 0; q < W; ++q) {
             if (q == R) continue;
-            if (send_cnt[q] > 0) {
-                double *blk = c->d_sendbuf + (size_t)send_off[q] * (d + 1);
-                for (int k = 0; k <= d; ++k)
-                    NCCLC(c, ncclSend(blk + (size_t)k * send_cnt[q], (size_t)send_cnt[q], ncclDouble, q, comm, c->stream));
-            }
-            const int64_t lo = imax(out_base_all[q], R * nl), hi = imin(out_base_all[q] + offspring_all[q], (R + 1) * nl);
-            if (hi > lo) {
-                const int64_t off = lo - R * nl, cnt = hi - lo;
-                for (int k = 0; k < d; ++k)
-                    NCCLC(c, ncclRecv(F.theta + (size_t)k * F.stride + off, (size_t)cnt, ncclDouble, q, comm, c->stream));
-                NCCLC(c, ncclRecv(F.lk + off, (size_t)cnt, ncclDouble, q, comm, c->stream));
-            }
+            if (send_cnt[q] > 0)
+                NCCLC(c, ncclSend(c->d_sendbuf + (size_t)send_off[q] * (d + 1), (size_t)send_cnt[q] * (d + 1), ncclDouble, q,
+                                  comm, c->stream));
+            if (recv_cnt[q] > 0)
+                NCCLC(c, ncclRecv(c->d_recvbuf + (size_t)recv_off[q] * (d + 1), (size_t)recv_cnt[q] * (d + 1), ncclDouble, q,
+                                  comm, c->stream));
         }
         NCCLC(c, ncclGroupEnd());
+        for (int q = 0; q < W; ++q) {
+            if (recv_cnt[q] == 0) continue;
+            const double *blk = c->d_recvbuf + (size_t)recv_off[q] * (d + 1);
+            const int64_t cnt = recv_cnt[q], off = recv_row[q];
+            for (int k = 0; k < d; ++k)
+                HIPC(c, hipMemcpyAsync(F.theta + (size_t)k * F.stride + off, blk + (size_t)k * cnt, (size_t)cnt * sizeof(double),
+                                       hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(F.lk + off, blk + (size_t)d * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice,
+                                   c->stream));
+        }
     }
     return 0;
 }

@@ -105,6 +105,8 @@ struct smc_ctx {
     int64_t n_tiles = 0;
     double *d_sendbuf = nullptr;     // (d+1) x capacity staging for remote offspring
     int64_t sendbuf_cap = 0;
+    double *d_recvbuf = nullptr;     // (d+1) x capacity staging for offspring arriving from peers
+    int64_t recvbuf_cap = 0;
     // sweep scratch: per (experiment, particle) sums of squared residuals and solver info, support
     // flags of the proposals, the global work counter of the persistent solve kernel
     double *d_sum_r2 = nullptr;
