@@ -337,7 +337,7 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     {
         unsigned long long h[16];
         MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
-        static const char *nm[8] = {"build+factor", "residual", "forward", "backward", "total", "change_D", "predict+Dupd", "newton+errtest"};
+        static const char *nm[8] = {"build+factor", "residual", "forward", "backward", "total", "change_D", "predict+Dupd", "jac+transpose"};
         fprintf(stderr, "[meth profile] solves %lld  nlu/solve %.1f  newton/solve %.1f  steps/solve %.1f\n", (long long)n_solves,
                 (double)h[4] / n_solves, (double)h[3] / n_solves, (double)h[0] / n_solves);
         for (int q = 0; q < 8; ++q)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "meth_dae_wave.h"
+#include "meth_dae_elem.h"
 #include "philox.h"
 #include "prior.h"
 #include "smc_internal.h"
@@ -16,19 +17,34 @@ namespace smc {
 
 using namespace meth;
 
-// K8 over (particle, experiment) pairs of the resident set; one wave per solve, persistent waves.
+// work list of an MH sweep: the (particle, experiment) pairs of proposals inside the prior support; queue[1] counts them
+__global__ void meth_worklist_kernel(const uint8_t *__restrict__ p0mask, int64_t n, int n_data, int64_t *__restrict__ list,
+                                     unsigned long long *__restrict__ queue) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n || p0mask[p] == 0) return;   // masked proposal: lk2 == lk1, nothing to solve
+    const unsigned long long base = atomicAdd(&queue[1], (unsigned long long)n_data);
+    for (int e = 0; e < n_data; ++e) list[base + e] = p * n_data + e;
+}
+
+// K8 over (particle, experiment) pairs of the resident set; one wave per solve (meth_dae_elem.h), persistent waves
+// that take solves from an atomic counter (a failed solve costs ~9 ordinary ones).  list == nullptr: all n * n_data
+// pairs; otherwise the queue[1] pairs of the work list.  Every wave leaves after at most count + 1 dequeues.
 __global__ void __launch_bounds__(64)
 meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
-                          const uint8_t *__restrict__ p0mask, double *__restrict__ flows, int *__restrict__ status,
-                          SweepCounters *__restrict__ counters) {
-    extern __shared__ double sD[];
+                          const int64_t *__restrict__ list, double *__restrict__ flows, int *__restrict__ status,
+                          SweepCounters *__restrict__ counters, unsigned long long *__restrict__ queue) {
+    extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const DView D{sD, lane};
-    const int64_t total = n * m.n_data;
-    for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const DViewE D{lds + kLdsD, lane};
+    const int64_t count = list ? (int64_t)queue[1] : n * m.n_data;
+    for (int64_t it = 0; it <= count; ++it) {
+        unsigned long long nxt = 0;
+        if (lane == 0) nxt = atomicAdd(&queue[0], 1ULL);
+        const int64_t pos = (int64_t)__shfl(nxt, 0);
+        if (pos >= count) break;
+        const int64_t w = list ? list[pos] : pos;
         const int64_t particle = w / m.n_data;
         const int e = (int)(w - particle * m.n_data);
-        if (p0mask && p0mask[particle] == 0) continue;   // masked proposal: lk2 == lk1, nothing to solve
         double p[18];
         for (int q = 0; q < 10; ++q) p[q] = m.cond[e * 10 + q];
         for (int j = 0; j < 8; ++j) {  // p_pred_bases[:, est_position] = particle (methanation_functions.py:80)
@@ -43,7 +59,7 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
                 for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
             }
         DaeStats st;
-        dae_wave_integrate(sD, lane, p, m.tf, m.rtol, m.atol, m.h0, 3000, st);
+        dae_elem_integrate(lds, lane, p, m.tf, m.rtol, m.atol, m.h0, 3000, st);
         if (lane == kNX - 1) {
             const double u = D(0, 6), T = D(0, 5);
             const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
@@ -182,8 +198,15 @@ static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int
     if (nwaves > n * m.n_data) nwaves = n * m.n_data;
     if (nwaves < 1) nwaves = 1;
     ScopedTimer tm(ctx, SMC_T_SOLVE);
-    hipLaunchKernelGGL(meth_particles_dae_kernel, dim3((unsigned)nwaves), dim3(64), 8 * 7 * 64 * sizeof(double), ctx->stream,
-                       m, theta, stride, n, p0mask, ctx->d_mflows, ctx->d_mstatus, ctx->d_counters);
+    (void)hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    const int64_t *list = nullptr;
+    if (p0mask) {
+        hipLaunchKernelGGL(meth_worklist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p0mask, n,
+                           m.n_data, ctx->d_mwork, ctx->d_queue);
+        list = ctx->d_mwork;
+    }
+    hipLaunchKernelGGL(meth_particles_dae_kernel, dim3((unsigned)nwaves), dim3(64), kLdsDoubles * sizeof(double), ctx->stream,
+                       m, theta, stride, n, list, ctx->d_mflows, ctx->d_mstatus, ctx->d_counters, ctx->d_queue);
 }
 
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk) {

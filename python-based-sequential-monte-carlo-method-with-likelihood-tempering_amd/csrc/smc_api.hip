@@ -133,7 +133,7 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->r_ac, (size_t)n_local));
     CK(hipMemsetAsync(c->r_ac, 0, (size_t)n_local, c->stream));
     CK(hipMalloc(&c->d_counters, sizeof(SweepCounters)));
-    CK(hipMalloc(&c->d_queue, sizeof(unsigned long long)));
+    CK(hipMalloc(&c->d_queue, 2 * sizeof(unsigned long long)));
     CK(hipMalloc(&c->d_p0, (size_t)n_local));
     {
         hipDeviceProp_t prop;
@@ -204,6 +204,7 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_mflows);
     (void)hipFree(c->d_mlk2);
     (void)hipFree(c->d_mstatus);
+    (void)hipFree(c->d_mwork);
     (void)hipFree(c->d_hb_theta);
     (void)hipFree(c->d_hb_lk);
     (void)hipFree(c->d_hb_pred);
@@ -274,7 +275,8 @@ int smc_set_model_methanation(smc_ctx *c, const double *cond, const double *gues
         if (est_position[q] < 0 || est_position[q] > 8) return fail(c, "est_position entries must be 0..8");
     HIPC(c, hipSetDevice(c->device));
     (void)hipFree(c->d_mcond); (void)hipFree(c->d_mguess); (void)hipFree(c->d_mobs); (void)hipFree(c->d_mflows);
-    (void)hipFree(c->d_mlk2); (void)hipFree(c->d_mstatus);
+    (void)hipFree(c->d_mlk2); (void)hipFree(c->d_mstatus); (void)hipFree(c->d_mwork);
+    c->d_mwork = nullptr;
     c->d_mcond = c->d_mguess = c->d_mobs = c->d_mflows = c->d_mlk2 = nullptr;
     c->d_mstatus = nullptr;
     HIPC(c, hipMalloc(&c->d_mcond, (size_t)n_data * 10 * 8));
@@ -283,6 +285,7 @@ int smc_set_model_methanation(smc_ctx *c, const double *cond, const double *gues
     HIPC(c, hipMalloc(&c->d_mflows, (size_t)c->n_local * n_data * 5 * 8));
     HIPC(c, hipMalloc(&c->d_mlk2, (size_t)c->n_local * 8));
     HIPC(c, hipMalloc(&c->d_mstatus, (size_t)c->n_local * n_data * sizeof(int)));
+    HIPC(c, hipMalloc(&c->d_mwork, (size_t)c->n_local * n_data * sizeof(int64_t)));
     HIPC(c, hipMemcpyAsync(c->d_mcond, cond, (size_t)n_data * 10 * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->d_mguess, guess, (size_t)n_data * 357 * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->d_mobs, obs, (size_t)n_data * 5 * 8, hipMemcpyHostToDevice, c->stream));

@@ -85,6 +85,7 @@ struct smc_ctx {
     smc::MethModel meth{};
     double *d_mcond = nullptr, *d_mguess = nullptr, *d_mobs = nullptr, *d_mflows = nullptr, *d_mlk2 = nullptr;
     int *d_mstatus = nullptr;
+    int64_t *d_mwork = nullptr;      // work list of an MH sweep: (particle, experiment) pairs of live proposals
     bool have_model = false, have_prior = false;
     smc::MMModel mm{};
     double *d_t = nullptr, *d_P = nullptr, *d_S0 = nullptr;
