@@ -80,6 +80,8 @@ __device__ __forceinline__ double allsum_across8(double v) {
     }
     return v;
 }
+// all 64 lanes (DPP + permlane swaps instead of six ds_bpermute rounds)
+__device__ __forceinline__ double allsum_wave(double v) { return allsum_across8(allsum_group8(v)); }
 template <int Q>
 __device__ __forceinline__ double allsum_over_mc(double v) {   // Q = node parity: the column index is c (0) or r (1)
     if (Q == 0) return allsum_group8(v);
@@ -93,6 +95,11 @@ struct ElemLane {   // lane = 8 r + c
     template <int Q> __device__ __forceinline__ int mc() const { return Q ? r : c; }   // block column
 };
 __device__ __forceinline__ int min6(int v) { return v < 6 ? v : 6; }
+__device__ __forceinline__ double ipow_small(double x, int n) {   // x^n, 1 <= n <= kNewtonMaxIter
+    double r = x;
+    for (int q = 1; q < n; ++q) r *= x;
+    return r;
+}
 
 // reciprocal of a wave-uniform value: v_rcp_f64 (2^-24) + one Newton step (2^-48: the iteration matrix of a
 // modified Newton method needs no more)
@@ -123,7 +130,7 @@ __device__ __forceinline__ bool elem_factor_node(const ElemLane &L, const double
     // The next pivot element always takes the generic update, so its reciprocal starts from `gen` and runs
     // beside the selects and the pivot row / column exchange of the next round (two chains instead of one).
     double akk = lane_bcast(a, 0);
-#pragma unroll 1
+    SMC_UNROLL
     for (int kk = 0; kk < 7; ++kk) {
         if (!(fabs(akk) > 1e-300) || !(fabs(akk) < 1e300)) ok = 0;
         const double p = recip1(akk);
@@ -209,45 +216,41 @@ __device__ __forceinline__ bool elem_build_and_factor(int lane, double *lds, con
     return __all(ok);
 }
 
+// Forward scan, tail-recursive over the nodes: z_I = X_I (b_I - L_I z_{I-1}).  The right-hand side and the L
+// coefficients of node I+1 are loaded BEFORE z_I is stored (the compiler must assume the store aliases them, and an
+// LDS round trip on the chain costs as much as the butterfly).  Returns z_50[mr] on every lane.
 template <int I>
-struct ElemForward {   // z_I = X_I (b_I - L_I z_{I-1}); returns z_I[mr] on every lane
+struct ElemForward {
     static __device__ __forceinline__ double run(const ElemLane &L, const double *cf, const double *b, double *z,
-                                                 const double (&X)[kNX]) {
-        constexpr int Q = I & 1;
+                                                 const double (&X)[kNX], double zprev, double bI, double ldI, double lxI) {
+        constexpr int Q = I & 1, QN = 1 - Q, IN = (I + 1 < kNX) ? I + 1 : I;
         const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
-        double t = b[I * 7 + min6(mc)];
+        const int mcn = min6(L.template mc<QN>());
+        const double bN = b[IN * 7 + mcn], ldN = cf[IN * 24 + mcn], lxN = cf[IN * 24 + 8 + mcn];
+        double t = bI;
         if (I > 0) {
-            const double zprev = ElemForward<I - 1>::run(L, cf, b, z, X);   // z_{I-1}[mc]
             const double z6 = lane_bcast(zprev, Q ? 48 : 6), z5 = lane_bcast(zprev, Q ? 40 : 5);
             const double zx = (mc == 6) ? z5 : z6;
-            const double *cfi = cf + I * 24;
-            t = fma(-cfi[8 + min6(mc)], zx, fma(-cfi[min6(mc)], zprev, t));
+            t = fma(-lxI, zx, fma(-ldI, zprev, t));
         }
         const double zi = allsum_over_mc<Q>(X[I] * t);
         if (mc == 0 && mr < 7) z[I * 7 + mr] = zi;
-        return zi;
+        if constexpr (I + 1 < kNX) return ElemForward<IN>::run(L, cf, b, z, X, zi, bN, ldN, lxN);
+        else return zi;
     }
-};
-template <>
-struct ElemForward<-1> {
-    static __device__ __forceinline__ double run(const ElemLane &, const double *, const double *, double *,
-                                                 const double (&)[kNX]) { return 0.0; }
 };
 
+// Backward scan: x_I = z_I - G_I x_{I+1}, I = 49 .. 0; `xnext` is x_{I+1}[mc], zI = z_I[mr] (loaded one step ahead)
 template <int I>
-struct ElemBackward {   // x_I = z_I - G_I x_{I+1}, I = 49 .. 0; `xnext` is x_{I+1}[mc]
-    static __device__ __forceinline__ void run(const ElemLane &L, double *z, const double (&G)[kNX], double xnext) {
-        constexpr int Q = I & 1;
+struct ElemBackward {
+    static __device__ __forceinline__ void run(const ElemLane &L, double *z, const double (&G)[kNX], double xnext, double zI) {
+        constexpr int Q = I & 1, QN = 1 - Q, IN = (I > 0) ? I - 1 : 0;
         const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
-        const double zi = z[I * 7 + min6(mr)];
-        const double xi = zi - allsum_over_mc<Q>(G[I] * xnext);
+        const double zN = z[IN * 7 + min6(L.template mr<QN>())];
+        const double xi = zI - allsum_over_mc<Q>(G[I] * xnext);
         if (mc == 0 && mr < 7) z[I * 7 + mr] = xi;
-        ElemBackward<I - 1>::run(L, z, G, xi);
+        if constexpr (I > 0) ElemBackward<IN>::run(L, z, G, xi, zN);
     }
-};
-template <>
-struct ElemBackward<-1> {
-    static __device__ __forceinline__ void run(const ElemLane &, double *, const double (&)[kNX], double) {}
 };
 
 // one modified-Newton iteration; returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
@@ -279,9 +282,9 @@ __device__ __forceinline__ double elem_newton_iteration(int lane, double *lds, d
     if (!__all(finite)) return -1.0;
     wave_lds_sync();
     SMC_PROF_ADD(st, 1);
-    const double zlast = ElemForward<kNX - 1>::run(L, cf, b, z, X);
+    const double zlast = ElemForward<0>::run(L, cf, b, z, X, 0.0, b[min6(L.c)], 0.0, 0.0);
     SMC_PROF_ADD(st, 2);
-    ElemBackward<kNX - 2>::run(L, z, G, zlast);
+    ElemBackward<kNX - 2>::run(L, z, G, zlast, z[(kNX - 2) * 7 + min6(L.template mr<(kNX - 2) & 1>())]);
     wave_lds_sync();
     SMC_PROF_ADD(st, 3);
     double sumsq = 0.0;
@@ -296,7 +299,7 @@ __device__ __forceinline__ double elem_newton_iteration(int lane, double *lds, d
             dd[f] += dx;
         }
     wave_lds_sync();
-    return sqrt(wave_allsum(sumsq) / kNS);
+    return sqrt(allsum_wave(sumsq) / kNS);
 }
 
 // bdf.py compute_R / change_D with static loops (no scratch): D[0..order] <- (R(factor) U)^T D[0..order].
@@ -401,6 +404,8 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
         }
         // The factored iteration matrix is kept while c = h/alpha_k is unchanged; rebuilt at the current predictor when
         // c changed, or - by repeating this attempt - when Newton stalled on a stale matrix (bdf.py:343-357).
+        // (IDA's policy of also keeping it while c drifts by < 25 %, with the correction scaled by 2/(1+cjratio), cut the
+        // factorisations from 100 to 63 per solve but raised the Newton iterations from 720 to 913: slower in total.)
         const bool fresh = !lu_valid || c != c_lu || force_rebuild;
         SMC_PROF_ADD(st, 6);
         if (fresh) {
@@ -422,7 +427,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
                 ++st.newton_iters;
                 if (dy_norm < 0) break;
                 const double rate = (dy_norm_old >= 0) ? dy_norm / dy_norm_old : -1.0;
-                if (rate >= 0 && (rate >= 1 || pow(rate, kNewtonMaxIter - kk) / (1 - rate) * dy_norm > newton_tol)) break;
+                if (rate >= 0 && (rate >= 1 || ipow_small(rate, kNewtonMaxIter - kk) / (1 - rate) * dy_norm > newton_tol)) break;
                 if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = true; break; }
                 dy_norm_old = dy_norm;
             }
@@ -448,7 +453,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
                 const double e = bdf_error_const(order) * dd[f] / sc;
                 se += e * e;
             }
-        const double error_norm = sqrt(wave_allsum(se) / (6 * kNX));
+        const double error_norm = sqrt(allsum_wave(se) / (6 * kNX));
         if (!(error_norm <= 1)) {
             ++st.rejects;
             const double factor = (error_norm == error_norm) ? fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1))) : 0.2;
@@ -492,8 +497,8 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
         SMC_PROF_ADD(st, 6);   // D update shares the predictor slot
         if (!select) continue;
         const double inf = __longlong_as_double(0x7ff0000000000000LL);
-        const double em = (order > 1) ? sqrt(wave_allsum(sm) / (6 * kNX)) : inf;
-        const double ep = (order < kMaxOrder) ? sqrt(wave_allsum(sp) / (6 * kNX)) : inf;
+        const double em = (order > 1) ? sqrt(allsum_wave(sm) / (6 * kNX)) : inf;
+        const double ep = (order < kMaxOrder) ? sqrt(allsum_wave(sp) / (6 * kNX)) : inf;
         const double fm = pow(em, -1.0 / order), f0 = pow(error_norm, -1.0 / (order + 1)), fp = pow(ep, -1.0 / (order + 2));
         double best = fm;
         int delta = -1;
