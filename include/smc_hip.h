@@ -44,6 +44,13 @@ extern "C" {
 
 #define SMC_PRIOR_UNIFORM 0 /* {"dist":"uniform","low","high"}  Micmem_settings.py:63-67 */
 #define SMC_PRIOR_NORMAL 1  /* {"dist":"normal","mu","sigma"}   Micmem_settings.py:55-59 */
+#define SMC_PRIOR_FLAT 2    /* no factor in cal_prior (sigma under normal_pred without taylor,
+                             * methanation_functions.py:132-138 multiplies num_est_params-1 densities) */
+
+/* what the Metropolis acceptance does with the prior */
+#define SMC_PRIOR_MODE_MASK 0        /* pp = exp(px*g) * p0            Micmem_SMC_main.py:224-233, SMC_methanation_main.py:376-389 */
+#define SMC_PRIOR_MODE_RATIO_MASK 1  /* pp = exp(px*g) * (p0_2/p0_1) * p0   SMC_methanation_main.py:320-349 (normal_pred, taylor) */
+#define SMC_PRIOR_MODE_RATIO 2       /* pp = exp(px*g) * (p0_2/p0_1), no reset of proposals   :358-374 (normal_pred) */
 
 typedef struct smc_ctx smc_ctx;
 
@@ -75,10 +82,12 @@ int smc_set_model_mm(smc_ctx *ctx, const double *t, const double *P_obs, const d
 int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *guess, const double *obs, int n_data,
                               const double *base_params, const int *est_position, int est_sigma, double sigma_fixed,
                               double tf, double rtol, double atol);
-/* Independent priors, one per parameter: kind[i] in {SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL}; (a,b) =
+/* Independent priors, one per parameter: kind[i] in {SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL, SMC_PRIOR_FLAT}; (a,b) =
  * (low,high) or (mu,sigma).  Used by the support mask of cal_prior (Micmem_SMC_main.py:60-90,
  * 224-228) and by smc_sample_prior_device. */
 int smc_set_prior(smc_ctx *ctx, const int *kind, const double *a, const double *b, int dim);
+/* SMC_PRIOR_MODE_*: default SMC_PRIOR_MODE_MASK (the live branch of both reference drivers). */
+int smc_set_prior_mode(smc_ctx *ctx, int mode);
 
 /* ---- particle movement -------------------------------------------------------------------- */
 int smc_upload_particles(smc_ctx *ctx, int set, const double *aos, int64_t n);   /* (n,d) -> SoA */

@@ -151,7 +151,7 @@ def sample_prior(priors: dict, n_particle: int) -> np.ndarray:
     """Micmem_settings.py:69-87: one draw of size N per parameter, parameter-major, global RNG."""
     p_pred = np.zeros((n_particle, len(priors)))
     for j, (name, p) in enumerate(priors.items()):
-        if p["dist"] == "normal":
+        if p["dist"] in ("normal", "flat"):
             p_pred[:, j] = np.random.normal(loc=p["mu"], scale=p["sigma"], size=n_particle)
         elif p["dist"] == "uniform":
             p_pred[:, j] = np.random.uniform(low=p["low"], high=p["high"], size=n_particle)
@@ -170,6 +170,8 @@ def cal_prior(theta: np.ndarray, priors: dict) -> np.ndarray:
             pdf_vals[:, j] = scipy.stats.norm.pdf(x, loc=cfg["mu"], scale=cfg["sigma"])
         elif cfg["dist"] == "uniform":
             pdf_vals[:, j] = scipy.stats.uniform.pdf(x, loc=cfg["low"], scale=cfg["high"] - cfg["low"])
+        elif cfg["dist"] == "flat":   # no factor: sigma under normal_pred without taylor (methanation_functions.py:132-138)
+            pdf_vals[:, j] = 1.0
         else:
             raise ValueError(f"Unknown prior: {cfg['dist']}")
     return np.prod(pdf_vals, axis=1)
@@ -416,12 +418,22 @@ def run_smc(data: MMData, s: SMCSettings | None = None, seed: int | None = 20250
             p_pred = p_filt + noise * mhstep_ratio
             p0_2 = cal_prior(p_pred, s.priors)     # :225
             p0 = np.int32(p0_2 > 0)                # :226
-            p_pred = p_pred * p0[:, None] + p_filt * (1.0 - p0[:, None])   # :228
+            prior_mode = getattr(s, "prior_mode", "mask")
+            if prior_mode != "mask":               # SMC_methanation_main.py:323-324 / :359-360
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    pratio = p0_2 / cal_prior(p_filt, s.priors)
+            if prior_mode != "ratio":
+                p_pred = p_pred * p0[:, None] + p_filt * (1.0 - p0[:, None])   # :228
             lk2 = sim_particle(p_pred)             # :229
             n_mutation_sweeps += 1
             px = lk2 - lk1                         # :231
             with np.errstate(over="ignore"):
-                pp = np.exp(px * gamma_new) * p0   # :233
+                if prior_mode == "mask":
+                    pp = np.exp(px * gamma_new) * p0   # :233
+                elif prior_mode == "ratio_mask":
+                    pp = np.exp(px * gamma_new) * pratio * p0    # SMC_methanation_main.py:343
+                else:
+                    pp = np.exp(px * gamma_new) * pratio         # SMC_methanation_main.py:367
             rr = np.random.uniform(0, 1, n_particle)   # :235
             r = np.int32(pp >= rr)                 # :236
             p_filt = p_pred * r[:, None] + p_filt * (1.0 - r[:, None])   # :238

@@ -14,7 +14,9 @@ LIB_PATH = os.path.join(_HERE, "libsmc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "smc_hip.h")
 
 SMC_SET_PRED, SMC_SET_FILT = 0, 1
-SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL = 0, 1
+SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL, SMC_PRIOR_FLAT = 0, 1, 2
+SMC_PRIOR_MODE_MASK, SMC_PRIOR_MODE_RATIO_MASK, SMC_PRIOR_MODE_RATIO = 0, 1, 2
+PRIOR_MODES = {"mask": 0, "ratio_mask": 1, "ratio": 2}
 SMC_MAX_ESS_CAND = 16
 SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX, SMC_T_SOLVE = range(7)
 TIMING_NAMES = {SMC_T_LOGLIK: "loglik", SMC_T_MH: "mh", SMC_T_ESS: "ess", SMC_T_RESAMPLE: "resample",
@@ -43,6 +45,7 @@ SIGNATURES = {
     "smc_set_model_mm": (cint, [c_ctx, c_dp, c_dp, c_dp, cint, cint, cint, f64, f64, f64]),
     "smc_set_model_methanation": (cint, [c_ctx, c_dp, c_dp, c_dp, cint, c_dp, c_ip, cint, f64, f64, f64, f64]),
     "smc_set_prior": (cint, [c_ctx, c_ip, c_dp, c_dp, cint]),
+    "smc_set_prior_mode": (cint, [c_ctx, cint]),
     "smc_upload_particles": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_download_particles": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_upload_lk": (cint, [c_ctx, cint, c_dp, i64]),

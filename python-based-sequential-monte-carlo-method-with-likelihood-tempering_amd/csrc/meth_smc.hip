@@ -135,7 +135,15 @@ generic_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt
         const double q = prior_pdf(prior.kind[c], prior.a[c], prior.b[c], cand[c]);
         pdf = (c == 0) ? q : pdf * q;
     }
-    const double p0 = (pdf > 0.0) ? 1.0 : 0.0, q0 = 1.0 - p0;
+    if (mh.prior_mode != SMC_PRIOR_MODE_MASK) {   // p0_2 / p0_1 (SMC_methanation_main.py:323-324, 343)
+        double cur_pdf = 1.0;
+        for (int c = 0; c < d; ++c) {
+            const double q = prior_pdf(prior.kind[c], prior.a[c], prior.b[c], cur[c]);
+            cur_pdf = (c == 0) ? q : cur_pdf * q;
+        }
+        mh.pratio[p] = pdf / cur_pdf;
+    }
+    const double p0 = (pdf > 0.0 || mh.prior_mode == SMC_PRIOR_MODE_RATIO) ? 1.0 : 0.0, q0 = 1.0 - p0;
     for (int c = 0; c < d; ++c) prop[c * pstride + p] = __dadd_rn(__dmul_rn(cand[c], p0), __dmul_rn(cur[c], q0));
     p0_out[p] = (uint8_t)(p0 != 0.0);
 }
@@ -160,7 +168,9 @@ generic_accept_kernel(MHParams mh, const double *__restrict__ prop, int64_t pstr
         } else {
             rr = mh.rr[p];
         }
-        const double pp = exp((lk2 - lk1) * mh.gamma) * p0;
+        double pp = exp((lk2 - lk1) * mh.gamma);
+        if (mh.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * mh.pratio[p];
+        if (mh.prior_mode != SMC_PRIOR_MODE_RATIO) pp = pp * p0;
         const double r = (pp >= rr) ? 1.0 : 0.0, nr = 1.0 - r;
         for (int c = 0; c < d; ++c) {
             const double th = prop[c * pstride + p], f = filt[c * fstride + p];

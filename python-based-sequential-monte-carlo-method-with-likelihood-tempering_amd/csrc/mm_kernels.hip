@@ -69,7 +69,13 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
     double pdf = prior_pdf(prior.kind[0], prior.a[0], prior.b[0], c0);
     pdf = pdf * prior_pdf(prior.kind[1], prior.a[1], prior.b[1], c1);
     pdf = pdf * prior_pdf(prior.kind[2], prior.a[2], prior.b[2], c2);
-    const double p0 = (pdf > 0.0) ? 1.0 : 0.0, q0 = 1.0 - p0;
+    if (mh.prior_mode != SMC_PRIOR_MODE_MASK) {   // p0_2 / p0_1 (SMC_methanation_main.py:323-324, 343)
+        double cur = prior_pdf(prior.kind[0], prior.a[0], prior.b[0], f0);
+        cur = cur * prior_pdf(prior.kind[1], prior.a[1], prior.b[1], f1);
+        cur = cur * prior_pdf(prior.kind[2], prior.a[2], prior.b[2], f2);
+        mh.pratio[p] = pdf / cur;
+    }
+    const double p0 = (pdf > 0.0 || mh.prior_mode == SMC_PRIOR_MODE_RATIO) ? 1.0 : 0.0, q0 = 1.0 - p0;
     prop[p] = __dadd_rn(__dmul_rn(c0, p0), __dmul_rn(f0, q0));
     prop[pstride + p] = __dadd_rn(__dmul_rn(c1, p0), __dmul_rn(f1, q0));
     prop[2 * pstride + p] = __dadd_rn(__dmul_rn(c2, p0), __dmul_rn(f2, q0));
@@ -255,7 +261,9 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                 rr = mh.rr[p];
             }
             const double px = lk2 - lk1;
-            const double pp = exp(px * mh.gamma) * p0;
+            double pp = exp(px * mh.gamma);
+            if (mh.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * mh.pratio[p];
+            if (mh.prior_mode != SMC_PRIOR_MODE_RATIO) pp = pp * p0;
             const double r = (pp >= rr) ? 1.0 : 0.0;
             const double nr = 1.0 - r;
             for (int c = 0; c < 3; ++c) {

@@ -12,6 +12,7 @@ __device__ __forceinline__ double prior_quiet_nan() { return __longlong_as_doubl
 //   uniform: support mask on the standardised value y = (x-loc)/scale, closed interval [0,1];
 //   normal : exp(-y^2/2)/sqrt(2*pi)/scale.
 __device__ __forceinline__ double prior_pdf(int kind, double a, double b, double x) {
+    if (kind == SMC_PRIOR_FLAT) return 1.0;
     if (kind == SMC_PRIOR_UNIFORM) {
         const double scale = b - a;
         const double y = (x - a) / scale;

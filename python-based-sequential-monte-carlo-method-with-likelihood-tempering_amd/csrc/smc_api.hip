@@ -197,6 +197,7 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_sum_r2);
     (void)hipFree(c->d_info);
     (void)hipFree(c->d_p0);
+    (void)hipFree(c->d_pratio);
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_mcond);
     (void)hipFree(c->d_mguess);
@@ -308,13 +309,24 @@ int smc_set_prior(smc_ctx *c, const int *kind, const double *a, const double *b,
     if (!c) return fail(nullptr, "NULL context");
     if (dim != c->dim) return fail(c, "smc_set_prior: dim mismatch");
     for (int i = 0; i < dim; ++i) {
-        if (kind[i] != SMC_PRIOR_UNIFORM && kind[i] != SMC_PRIOR_NORMAL) return fail(c, "Unknown prior kind");
+        if (kind[i] != SMC_PRIOR_UNIFORM && kind[i] != SMC_PRIOR_NORMAL && kind[i] != SMC_PRIOR_FLAT)
+            return fail(c, "Unknown prior kind");
         c->prior.kind[i] = kind[i];
         c->prior.a[i] = a[i];
         c->prior.b[i] = b[i];
     }
     c->prior.d = dim;
     c->have_prior = true;
+    return 0;
+}
+
+int smc_set_prior_mode(smc_ctx *c, int mode) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (mode != SMC_PRIOR_MODE_MASK && mode != SMC_PRIOR_MODE_RATIO_MASK && mode != SMC_PRIOR_MODE_RATIO)
+        return fail(c, "Unknown prior mode");
+    HIPC(c, hipSetDevice(c->device));
+    if (mode != SMC_PRIOR_MODE_MASK && !c->d_pratio) HIPC(c, hipMalloc(&c->d_pratio, (size_t)c->n_local * sizeof(double)));
+    c->prior_mode = mode;
     return 0;
 }
 
@@ -773,6 +785,8 @@ int smc_mh_step_host_rng(smc_ctx *c, double gamma, double mhstep_ratio, const do
     mh.noise = c->d_noise;
     mh.rr = c->d_rr;
     mh.device_rng = 0;
+    mh.prior_mode = c->prior_mode;
+    mh.pratio = c->d_pratio;
     {
         ScopedTimer tm(c, SMC_T_MH);
         if (c->model_kind == 2) launch_meth_mh(c, n, mh); else launch_mm_mh(c, n, mh);
@@ -791,6 +805,8 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
     mh.gamma = gamma;
     mh.ratio = mhstep_ratio;
     mh.device_rng = 1;
+    mh.prior_mode = c->prior_mode;
+    mh.pratio = c->d_pratio;
     mh.seed = seed;
     mh.stream = stream;
     mh.global_offset = global_offset;

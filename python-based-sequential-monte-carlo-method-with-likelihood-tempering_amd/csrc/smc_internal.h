@@ -56,6 +56,8 @@ struct MHParams {    // passed by value to the fused MH kernel
     uint64_t seed, stream;
     int64_t global_offset;
     int device_rng;
+    int prior_mode;       // SMC_PRIOR_MODE_*
+    double *pratio;       // prior_mode != MASK: p0_2 / p0_1 per particle (written by propose, read by accept)
 };
 
 struct SweepCounters {  // device-side integer counters (order-independent atomics)
@@ -114,6 +116,8 @@ struct smc_ctx {
     int *d_info = nullptr;
     int64_t item_cap = 0;            // particles the two arrays above can hold (x kMaxEx experiments)
     uint8_t *d_p0 = nullptr;
+    double *d_pratio = nullptr;      // prior density ratio of the proposals (allocated on first use)
+    int prior_mode = 0;
     unsigned long long *d_queue = nullptr;
     int cu_count = 0, solve_blocks_per_cu = 0;
     // debug capture of the last MH iteration (lk2, accept flags; proposals live in SMC_SET_PRED)

@@ -55,6 +55,7 @@ class SMCSettings:
     seed: int = 20250205
     rtol: float = 1e-3
     atol: float = 1e-6
+    prior_mode: str = "mask"          # "mask" | "ratio_mask" | "ratio"  (HipEngine.set_prior_mode)
     priors: dict = field(default_factory=lambda: {
         "Vmax": {"dist": "uniform", "low": 0, "high": 10},
         "Km": {"dist": "uniform", "low": 0, "high": 10},
@@ -78,7 +79,7 @@ def sample_prior(priors: dict, n_particle: int) -> np.ndarray:
     """Micmem_settings.py:69-87 - global NumPy RNG, one draw of size N per parameter, parameter-major."""
     p_pred = np.zeros((n_particle, len(priors)))
     for j, (name, p) in enumerate(priors.items()):
-        if p["dist"] == "normal":
+        if p["dist"] in ("normal", "flat"):
             p_pred[:, j] = np.random.normal(loc=p["mu"], scale=p["sigma"], size=n_particle)
         elif p["dist"] == "uniform":
             p_pred[:, j] = np.random.uniform(low=p["low"], high=p["high"], size=n_particle)
@@ -193,6 +194,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     assert n_local * world == n, "n_particle must equal world * n_local"
     lo = rank * n_local
     w_cov = s.w_cov()
+    engine.set_prior_mode(s.prior_mode)
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "particle_mutation_steps": 0}

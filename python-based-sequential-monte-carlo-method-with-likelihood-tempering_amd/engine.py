@@ -119,12 +119,22 @@ class HipEngine:
                 kinds.append(B.SMC_PRIOR_NORMAL)
                 a.append(p["mu"])
                 b.append(p["sigma"])
+            elif p["dist"] == "flat":       # drawn like a normal, no factor in the prior density
+                kinds.append(B.SMC_PRIOR_FLAT)
+                a.append(p["mu"])
+                b.append(p["sigma"])
             else:
                 raise ValueError(f"Unknown prior: {p['dist']}")
         k = np.array(kinds, dtype=np.int32)
         a = np.array(a, dtype=np.float64)
         b = np.array(b, dtype=np.float64)
         self._ck(self.L.smc_set_prior(self.ctx, k.ctypes.data_as(B.c_ip), _dp(a), _dp(b), len(kinds)), "smc_set_prior")
+
+    def set_prior_mode(self, mode):
+        """"mask" (default; the live branch of both reference drivers), "ratio_mask" (normal_pred and taylor,
+        SMC_methanation_main.py:320-349) or "ratio" (normal_pred, :358-374)."""
+        m = B.PRIOR_MODES[mode] if isinstance(mode, str) else int(mode)
+        self._ck(self.L.smc_set_prior_mode(self.ctx, m), "smc_set_prior_mode")
 
     # ---- movement ------------------------------------------------------------------------------
     def upload_particles(self, which, aos):

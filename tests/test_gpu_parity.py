@@ -372,6 +372,38 @@ def test_full_run_logz_matches_oracle(pkg, O, data):
     assert np.abs(out["p_pred"] - o["p_pred"]).max() < 1e-9
 
 
+@pytest.mark.parametrize("mode", ["ratio_mask", "ratio"])
+def test_full_run_prior_density_ratio_modes(pkg, O, data, mode):
+    """normal / mixed priors with the density ratio p0_2/p0_1 in the acceptance
+    (SMC_methanation_main.py:320-374; dead branches in the reference, so the pin is the oracle's restatement of those
+    lines on the same NumPy stream).  "ratio_mask": normal + uniform priors, proposals outside the support reset;
+    "ratio": normal priors with one parameter left out of the density (as sigma is in methanation_functions.py:132-138),
+    no reset."""
+    if mode == "ratio_mask":
+        priors = {"Vmax": {"dist": "normal", "mu": 3.0, "sigma": 0.7}, "Km": {"dist": "uniform", "low": 0, "high": 10},
+                  "sigma": {"dist": "uniform", "low": 0, "high": 10}}
+    else:   # everything stays > 4 prior sigmas away from 0 (sigma <= 0 gives logL = -inf and then -inf * 0 = NaN, main:240)
+        # without the reset a proposal may leave the domain of the model (Km < 0: the reference's solver raises), so
+        # the priors sit tightly around the posterior
+        priors = {"Vmax": {"dist": "flat", "mu": 1.3, "sigma": 0.1}, "Km": {"dist": "normal", "mu": 0.6, "sigma": 0.05},
+                  "sigma": {"dist": "normal", "mu": 0.0205, "sigma": 0.001}}
+    so = O.SMCSettings(priors=priors)
+    so.prior_mode = mode
+    o = O.run_smc(data, so, seed=11, n_threads=0, record_mh=False)
+    s = pkg.SMCSettings(seed=11, priors=priors, prior_mode=mode)
+    with make_engine(pkg, data, 1000, priors=priors) as eng:
+        out = pkg.run_smc(eng, s, rng="numpy", verbose=False)
+        eng.set_prior_mode("mask")
+    assert out["gamma"] == 1.0 and len(out["records"]) == len(o["records"])
+    assert np.array_equal([r["gamma_new"] for r in out["records"]], [r.gamma_new for r in o["records"]])
+    assert np.array_equal([r["n_accept"] for r in out["records"]], [r.n_accept for r in o["records"]])
+    assert np.abs(out["p_pred"] - o["p_pred"]).max() < 1e-9
+    assert relerr(out["lk"], o["lk"]).max() < TOL_LOGL
+    # the ratio does change the chain: the same run with the support mask alone ends elsewhere
+    o_mask = O.run_smc(data, O.SMCSettings(priors=priors), seed=11, n_threads=0, record_mh=False)
+    assert np.abs(o_mask["p_pred"] - o["p_pred"]).max() > 1e-6
+
+
 def test_full_run_device_rng_statistics(pkg, data, golden_run):
     """Device-RNG mode cannot share NumPy's stream; posterior moments must agree statistically with the
     reference posterior (N=1000): |mean_gpu - mean_ref| <= 5 * std / sqrt(1000) per parameter."""
