@@ -89,6 +89,14 @@ int smc_set_prior(smc_ctx *ctx, const int *kind, const double *a, const double *
 /* SMC_PRIOR_MODE_*: default SMC_PRIOR_MODE_MASK (the live branch of both reference drivers). */
 int smc_set_prior_mode(smc_ctx *ctx, int mode);
 
+/* Resampling scheme of smc_resample_phase1/2 (BASELINE.json names systematic resampling; the reference implements
+ * only the residual-systematic variant, Micmem_SMC_main.py:147-184, which stays the default):
+ *   SMC_RESAMPLE_RESIDUAL_SYSTEMATIC  trunc(N w_i) copies + systematic draws on the residuals
+ *   SMC_RESAMPLE_SYSTEMATIC           systematic draws on the weights themselves (thresholds (u + k)/N) */
+#define SMC_RESAMPLE_RESIDUAL_SYSTEMATIC 0
+#define SMC_RESAMPLE_SYSTEMATIC 1
+int smc_set_resampling(smc_ctx *ctx, int scheme);
+
 /* ---- particle movement -------------------------------------------------------------------- */
 int smc_upload_particles(smc_ctx *ctx, int set, const double *aos, int64_t n);   /* (n,d) -> SoA */
 int smc_download_particles(smc_ctx *ctx, int set, double *aos, int64_t n);

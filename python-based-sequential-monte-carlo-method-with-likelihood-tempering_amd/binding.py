@@ -17,6 +17,7 @@ SMC_SET_PRED, SMC_SET_FILT = 0, 1
 SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL, SMC_PRIOR_FLAT = 0, 1, 2
 SMC_PRIOR_MODE_MASK, SMC_PRIOR_MODE_RATIO_MASK, SMC_PRIOR_MODE_RATIO = 0, 1, 2
 PRIOR_MODES = {"mask": 0, "ratio_mask": 1, "ratio": 2}
+RESAMPLING = {"residual_systematic": 0, "systematic": 1}
 SMC_MAX_ESS_CAND = 16
 SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX, SMC_T_SOLVE = range(7)
 TIMING_NAMES = {SMC_T_LOGLIK: "loglik", SMC_T_MH: "mh", SMC_T_ESS: "ess", SMC_T_RESAMPLE: "resample",
@@ -46,6 +47,7 @@ SIGNATURES = {
     "smc_set_model_methanation": (cint, [c_ctx, c_dp, c_dp, c_dp, cint, c_dp, c_ip, cint, f64, f64, f64, f64]),
     "smc_set_prior": (cint, [c_ctx, c_ip, c_dp, c_dp, cint]),
     "smc_set_prior_mode": (cint, [c_ctx, cint]),
+    "smc_set_resampling": (cint, [c_ctx, cint]),
     "smc_upload_particles": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_download_particles": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_upload_lk": (cint, [c_ctx, cint, c_dp, i64]),

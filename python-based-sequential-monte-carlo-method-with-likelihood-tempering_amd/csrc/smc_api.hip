@@ -330,6 +330,13 @@ int smc_set_prior_mode(smc_ctx *c, int mode) {
     return 0;
 }
 
+int smc_set_resampling(smc_ctx *c, int scheme) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC && scheme != SMC_RESAMPLE_SYSTEMATIC) return fail(c, "Unknown resampling scheme");
+    c->resampling = scheme;
+    return 0;
+}
+
 // ---- particle movement -------------------------------------------------------------------------
 static int check_set(smc_ctx *c, int set, int64_t n) {
     if (!c) return fail(nullptr, "NULL context");

@@ -239,10 +239,16 @@ struct ResampleArgs {
     double n_global, inv_np;   // p_is = trunc(w*N); residual = w - p_is*inv_Np (:147,150)
     double wrand, base;        // wrand (:156); base = residual sum of all lower ranks
     int first_rank;            // this rank holds global particle 0
+    int scheme;                // SMC_RESAMPLE_*
 };
 
 __device__ __forceinline__ void resample_item(const ResampleArgs &a, double lk, double &resid, int64_t &cnt) {
     const double w = exp((lk - a.max_lk) * a.gm) / a.sum_w;
+    if (a.scheme == SMC_RESAMPLE_SYSTEMATIC) {   // no deterministic copies: the running sum is the cumulative weight
+        cnt = 0;
+        resid = w;
+        return;
+    }
     const double c = trunc(w * a.n_global);
     cnt = (int64_t)c;
     resid = w - c * a.inv_np;
@@ -508,6 +514,7 @@ static ResampleArgs make_args(smc_ctx *c, double max_lk, double gm, double sum_w
     a.wrand = wrand;
     a.base = base;
     a.first_rank = (c->rank == 0);
+    a.scheme = c->resampling;
     return a;
 }
 void launch_resample_phase1(smc_ctx *c, double max_lk, double gm, double sum_w) {

@@ -56,6 +56,9 @@ class SMCSettings:
     rtol: float = 1e-3
     atol: float = 1e-6
     prior_mode: str = "mask"          # "mask" | "ratio_mask" | "ratio"  (HipEngine.set_prior_mode)
+    resampling: str = "residual_systematic"   # | "systematic"  (HipEngine.set_resampling; the reference has only the first)
+    ess_search: str = "backoff"       # the reference's geometric back-off (main:111-144) | "bisection"
+    ess_bisect_tol: float = 1e-9      # bisection: bracket width in gamma at which the search stops
     priors: dict = field(default_factory=lambda: {
         "Vmax": {"dist": "uniform", "low": 0, "high": 10},
         "Km": {"dist": "uniform", "low": 0, "high": 10},
@@ -106,6 +109,8 @@ def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_
     """main:111-144.  Candidates are evaluated `chunk` at a time by one fused pass over lk each."""
     n = s.n_particle
     max_lk = float(comm.allreduce_max([engine.max_lk_local()])[0])            # :116
+    if s.ess_search == "bisection":
+        return ess_bisection(engine, comm, gamma_old, s, max_lk, chunk)
     gms, gammas, gamma_after_all = ess_candidates(gamma_old, s)
     iters = 0
     launches = 0
@@ -128,6 +133,48 @@ def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_
     # no candidate passed: the weights of the last trial are kept, gamma has been shrunk once more (:141-144)
     return {"gamma_new": gamma_after_all, "gm": gms[-1], "ess": ess, "sum_weight": sum_w, "max_lk": max_lk,
             "iters": iters, "launches": launches, "warning": True}
+
+
+def ess_bisection(engine, comm, gamma_old: float, s: SMCSettings, max_lk: float, chunk: int = SMC_MAX_ESS_CAND):
+    """The tempering increment at which ESS/N crosses ess_limit, located by sectioning (BASELINE.json: "adaptive
+    tempering via ESS bisection"; not in the reference, whose back-off shrinks the increment by 0.7 until the ESS
+    passes and so stops up to 30 % short).  Every pass over lk evaluates `chunk` increments at once, so the bracket
+    shrinks (chunk+1)-fold per launch.  Returns the largest increment found with ESS/N > ess_limit."""
+    n = s.n_particle
+    g_hi = min(1.0, gamma_old + s.d_gamma_max)
+    hi_gm = g_hi - gamma_old
+    state = {"iters": 0, "launches": 0}
+
+    def evaluate(gms):
+        sw, sw2 = engine.ess_partials(max_lk, list(gms))
+        state["launches"] += 1
+        state["iters"] += len(gms)
+        tot = comm.allreduce_sum(np.concatenate([sw, sw2]))
+        sw, sw2 = tot[:len(gms)], tot[len(gms):]
+        return sw, 1.0 / (sw2 / (sw * sw)) / n
+
+    sw, ess = evaluate([hi_gm])
+    if ess[0] > s.ess_limit:                       # the whole remaining increment passes
+        return {"gamma_new": g_hi, "gm": hi_gm, "ess": float(ess[0]), "sum_weight": float(sw[0]),   # g_hi: exactly 1.0 at the end
+                "max_lk": max_lk, "iters": state["iters"], "launches": state["launches"], "warning": False}
+    lo_gm, best = 0.0, None
+    while hi_gm - lo_gm > s.ess_bisect_tol:
+        gms = lo_gm + (hi_gm - lo_gm) * np.arange(1, chunk + 1) / (chunk + 1)
+        sw, ess = evaluate(gms)
+        ok = np.nonzero(ess > s.ess_limit)[0]
+        if len(ok):                                # ESS falls with gamma: the last passing point bounds from below
+            k = int(ok[-1])
+            best = (float(gms[k]), float(ess[k]), float(sw[k]))
+            lo_gm = float(gms[k])
+            hi_gm = float(gms[k + 1]) if k + 1 < len(gms) else hi_gm
+        else:
+            hi_gm = float(gms[0])
+    if best is None:                               # not even the smallest increment passes: take it, warn like :141-144
+        sw, ess = evaluate([hi_gm])
+        best = (hi_gm, float(ess[0]), float(sw[0]))
+    gm, e, w = best
+    return {"gamma_new": gamma_old + gm, "gm": gm, "ess": e, "sum_weight": w, "max_lk": max_lk,
+            "iters": state["iters"], "launches": state["launches"], "warning": e <= s.ess_limit}
 
 
 def resample(engine, comm, es: dict, wrand_u: float, s: SMCSettings, first_step: bool):
@@ -195,6 +242,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     lo = rank * n_local
     w_cov = s.w_cov()
     engine.set_prior_mode(s.prior_mode)
+    engine.set_resampling(s.resampling)
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "particle_mutation_steps": 0}

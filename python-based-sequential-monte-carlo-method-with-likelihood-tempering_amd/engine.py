@@ -136,6 +136,11 @@ class HipEngine:
         m = B.PRIOR_MODES[mode] if isinstance(mode, str) else int(mode)
         self._ck(self.L.smc_set_prior_mode(self.ctx, m), "smc_set_prior_mode")
 
+    def set_resampling(self, scheme):
+        """"residual_systematic" (default, Micmem_SMC_main.py:147-184) or "systematic"."""
+        k = B.RESAMPLING[scheme] if isinstance(scheme, str) else int(scheme)
+        self._ck(self.L.smc_set_resampling(self.ctx, k), "smc_set_resampling")
+
     # ---- movement ------------------------------------------------------------------------------
     def upload_particles(self, which, aos):
         aos = _f64(aos)

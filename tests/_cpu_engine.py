@@ -36,6 +36,12 @@ class OracleEngine:
         self.theta[PRED] = self.theta[FILT].copy()
         self.lk[PRED] = self.lk[FILT].copy()
 
+    def set_prior_mode(self, mode):           # the test double implements the reference's live branch only
+        assert mode in ("mask", 0)
+
+    def set_resampling(self, scheme):
+        assert scheme in ("residual_systematic", 0)
+
     def synchronize(self):
         pass
 

@@ -53,10 +53,15 @@ def test_two_rank_gloo_run_equals_single_process_oracle(O, data, n, seed):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, seed, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda x: x[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:                       # a rank that raised leaves its peer waiting in a collective: end both
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
     ref = O.run_smc(data, O.SMCSettings(n_particle=n), seed=seed, record_mh=False)
     p_all = np.concatenate([r[1] for r in res])
     lk_all = np.concatenate([r[2] for r in res])
