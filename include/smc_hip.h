@@ -92,9 +92,13 @@ int smc_set_prior_mode(smc_ctx *ctx, int mode);
 /* Resampling scheme of smc_resample_phase1/2 (BASELINE.json names systematic resampling; the reference implements
  * only the residual-systematic variant, Micmem_SMC_main.py:147-184, which stays the default):
  *   SMC_RESAMPLE_RESIDUAL_SYSTEMATIC  trunc(N w_i) copies + systematic draws on the residuals
- *   SMC_RESAMPLE_SYSTEMATIC           systematic draws on the weights themselves (thresholds (u + k)/N) */
+ *   SMC_RESAMPLE_SYSTEMATIC           systematic draws on the weights themselves (thresholds (u + k)/N)
+ *   SMC_RESAMPLE_MULTINOMIAL          N iid draws: the thresholds are the order statistics of N uniforms, produced on
+ *                                     the device as normalised partial sums of N+1 exponentials (Philox, seeded by
+ *                                     the bits of `wrand`); offspring land sorted by ancestor like the other schemes */
 #define SMC_RESAMPLE_RESIDUAL_SYSTEMATIC 0
 #define SMC_RESAMPLE_SYSTEMATIC 1
+#define SMC_RESAMPLE_MULTINOMIAL 2
 int smc_set_resampling(smc_ctx *ctx, int scheme);
 
 /* ---- particle movement -------------------------------------------------------------------- */

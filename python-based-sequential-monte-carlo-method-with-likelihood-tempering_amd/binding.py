@@ -17,7 +17,7 @@ SMC_SET_PRED, SMC_SET_FILT = 0, 1
 SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL, SMC_PRIOR_FLAT = 0, 1, 2
 SMC_PRIOR_MODE_MASK, SMC_PRIOR_MODE_RATIO_MASK, SMC_PRIOR_MODE_RATIO = 0, 1, 2
 PRIOR_MODES = {"mask": 0, "ratio_mask": 1, "ratio": 2}
-RESAMPLING = {"residual_systematic": 0, "systematic": 1}
+RESAMPLING = {"residual_systematic": 0, "systematic": 1, "multinomial": 2}
 SMC_MAX_ESS_CAND = 16
 SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX, SMC_T_SOLVE = range(7)
 TIMING_NAMES = {SMC_T_LOGLIK: "loglik", SMC_T_MH: "mh", SMC_T_ESS: "ess", SMC_T_RESAMPLE: "resample",

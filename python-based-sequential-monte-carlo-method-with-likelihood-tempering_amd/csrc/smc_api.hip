@@ -198,6 +198,8 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_info);
     (void)hipFree(c->d_p0);
     (void)hipFree(c->d_pratio);
+    (void)hipFree(c->d_mn_thr);
+    (void)hipFree(c->d_mn_blk);
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_mcond);
     (void)hipFree(c->d_mguess);
@@ -332,7 +334,14 @@ int smc_set_prior_mode(smc_ctx *c, int mode) {
 
 int smc_set_resampling(smc_ctx *c, int scheme) {
     if (!c) return fail(nullptr, "NULL context");
-    if (scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC && scheme != SMC_RESAMPLE_SYSTEMATIC) return fail(c, "Unknown resampling scheme");
+    if (scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC && scheme != SMC_RESAMPLE_SYSTEMATIC && scheme != SMC_RESAMPLE_MULTINOMIAL)
+        return fail(c, "Unknown resampling scheme");
+    if (scheme == SMC_RESAMPLE_MULTINOMIAL && !c->d_mn_thr) {
+        HIPC(c, hipSetDevice(c->device));
+        const int64_t m = c->n_global + 1, ntm = (m + kScanTile - 1) / kScanTile;
+        HIPC(c, hipMalloc(&c->d_mn_thr, (size_t)m * sizeof(double)));
+        HIPC(c, hipMalloc(&c->d_mn_blk, (size_t)(ntm + 1) * sizeof(double)));
+    }
     c->resampling = scheme;
     return 0;
 }

@@ -119,6 +119,8 @@ struct smc_ctx {
     double *d_pratio = nullptr;      // prior density ratio of the proposals (allocated on first use)
     int prior_mode = 0;
     int resampling = 0;              // SMC_RESAMPLE_*
+    double *d_mn_thr = nullptr;      // multinomial resampling: n_global + 1 thresholds
+    double *d_mn_blk = nullptr;      // ... and their per-tile sums
     unsigned long long *d_queue = nullptr;
     int cu_count = 0, solve_blocks_per_cu = 0;
     // debug capture of the last MH iteration (lk2, accept flags; proposals live in SMC_SET_PRED)

@@ -4,6 +4,8 @@
 // fixed order + a single-block final pass), so results are reproducible run to run.
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "philox.h"
 #include "smc_internal.h"
 #include "stage_kernels.h"
@@ -240,11 +242,13 @@ struct ResampleArgs {
     double wrand, base;        // wrand (:156); base = residual sum of all lower ranks
     int first_rank;            // this rank holds global particle 0
     int scheme;                // SMC_RESAMPLE_*
+    const double *thr;         // multinomial: the N sorted thresholds (order statistics of N uniforms)
+    int64_t n_thr;
 };
 
 __device__ __forceinline__ void resample_item(const ResampleArgs &a, double lk, double &resid, int64_t &cnt) {
     const double w = exp((lk - a.max_lk) * a.gm) / a.sum_w;
-    if (a.scheme == SMC_RESAMPLE_SYSTEMATIC) {   // no deterministic copies: the running sum is the cumulative weight
+    if (a.scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC) {   // no deterministic copies: the running sum is the cumulative weight
         cnt = 0;
         resid = w;
         return;
@@ -304,7 +308,60 @@ __global__ void __launch_bounds__(kScanBlock) tile_exclusive_scan_kernel(T *__re
 
 // number of systematic thresholds wrand + k/N (k >= 0) that are <= S   (:168-174)
 __device__ __forceinline__ int64_t thresholds_below(double S, const ResampleArgs &a) {
+    if (a.scheme == SMC_RESAMPLE_MULTINOMIAL) {   // upper_bound over the sorted thresholds
+        int64_t lo = 0, hi = a.n_thr;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.thr[mid] <= S) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    }
     return (S >= a.wrand) ? (int64_t)floor((S - a.wrand) * a.n_global) + 1 : 0;
+}
+
+// Multinomial thresholds: the order statistics of N iid uniforms are the normalised partial sums of N+1 iid
+// exponentials, U_(k) = (E_1 + .. + E_k) / (E_1 + .. + E_{N+1})  -  a scan instead of a sort, and every rank can
+// produce the same array from the seed.  thr[k] = E_{k+1} on exit of the first kernel, the partial sums divided by
+// the total after the second (thr[N] == 1 is not a threshold).
+__global__ void __launch_bounds__(kScanBlock) mn_spacings_kernel(uint64_t seed, uint64_t stream, int64_t m,
+                                                                 double *__restrict__ thr, double *__restrict__ blk) {
+    __shared__ double lds[4];
+    const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        if (i < m) {
+            const u32x4 r = philox_block(seed, (uint64_t)i, stream, 7);
+            const double e = -log(1.0 - u01_from(r.x, r.y));   // u in [0,1) -> e in [0, inf)
+            thr[i] = e;
+            s += e;
+        }
+    }
+    s = block_sum(s, lds);
+    if (threadIdx.x == 0) blk[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(kScanBlock) mn_thresholds_kernel(int64_t m, double *__restrict__ thr,
+                                                                   const double *__restrict__ blk_excl, int64_t nt) {
+    __shared__ double lds[4];
+    const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kScanItems;
+    double e[kScanItems], s = 0.0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        e[k] = (i < m) ? thr[i] : 0.0;
+        s += e[k];
+    }
+    double tile_total;
+    const double incl = block_inclusive_scan(s, lds, &tile_total);
+    double run = blk_excl[blockIdx.x] + (incl - s);
+    const double inv_total = 1.0 / blk_excl[nt];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        const int64_t i = base + k;
+        run += e[k];
+        if (i < m) thr[i] = run * inv_total;
+    }
 }
 
 // phase 2: systematic offspring from the running residual sum, per-tile inclusive offspring scan.
@@ -515,6 +572,8 @@ static ResampleArgs make_args(smc_ctx *c, double max_lk, double gm, double sum_w
     a.base = base;
     a.first_rank = (c->rank == 0);
     a.scheme = c->resampling;
+    a.thr = c->d_mn_thr;
+    a.n_thr = c->n_global;
     return a;
 }
 void launch_resample_phase1(smc_ctx *c, double max_lk, double gm, double sum_w) {
@@ -530,6 +589,16 @@ void launch_resample_phase2(smc_ctx *c, double max_lk, double gm, double sum_w, 
     ParticleSet &P = c->set[SMC_SET_PRED];
     const ResampleArgs a = make_args(c, max_lk, gm, sum_w, wrand, base);
     const int64_t nt = c->n_tiles;
+    if (c->resampling == SMC_RESAMPLE_MULTINOMIAL) {   // thresholds of this resampling: seeded by the bits of wrand
+        const int64_t m = c->n_global + 1, ntm = (m + kScanTile - 1) / kScanTile;
+        uint64_t seed;
+        memcpy(&seed, &wrand, sizeof seed);
+        hipLaunchKernelGGL(mn_spacings_kernel, dim3((unsigned)ntm), dim3(kScanBlock), 0, c->stream, seed,
+                           0x5EEDull << 32, m, c->d_mn_thr, c->d_mn_blk);
+        hipLaunchKernelGGL((tile_exclusive_scan_kernel<double>), dim3(1), dim3(kScanBlock), 0, c->stream, c->d_mn_blk, ntm);
+        hipLaunchKernelGGL(mn_thresholds_kernel, dim3((unsigned)ntm), dim3(kScanBlock), 0, c->stream, m, c->d_mn_thr,
+                           c->d_mn_blk, ntm);
+    }
     // d_blk_c is reused for the per-tile offspring totals
     hipLaunchKernelGGL(resample_offspring_kernel, dim3((unsigned)nt), dim3(kScanBlock), 0, c->stream, P.lk, c->n_local,
                        a, c->d_blk_r, c->d_oscan, c->d_blk_c);

@@ -434,6 +434,38 @@ def test_systematic_resampling_option(pkg, data):
     assert np.array_equal(anc[:len(src)], th[src])
 
 
+def test_multinomial_resampling_option(pkg, data):
+    """BASELINE.json names multinomial resampling (absent from the reference).  Statistical pin: over repeated
+    draws the offspring counts must have the multinomial mean N w_i AND variance N w_i (1 - w_i) - the systematic
+    schemes have variance < 1, so the second moment tells them apart - and always sum to N."""
+    n, reps = 2048, 400
+    th = mixed_particles(n, seed=5)
+    s = pkg.SMCSettings(n_particle=n, resampling="multinomial")
+    rs = np.random.RandomState(1)
+    with make_engine(pkg, data, n) as eng:
+        eng.set_resampling("multinomial")
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+        es = pkg.ess_search(eng, pkg.SingleComm(), 0.0, s)
+        offs = np.empty((reps, n))
+        for k in range(reps):
+            out = pkg.resample(eng, pkg.SingleComm(), es, float(rs.uniform()), s, k == 0)
+            offs[k] = eng.download_offspring()
+            assert out["n_offspring"] == n and offs[k].sum() == n
+        anc = eng.download_particles(pkg.SMC_SET_FILT)
+        eng.set_resampling("residual_systematic")
+    assert np.array_equal(anc, th[np.repeat(np.arange(n), offs[-1].astype(int))])
+    w = np.exp((lk - es["max_lk"]) * es["gm"])
+    w = w / w.sum()
+    heavy = np.argsort(w)[-40:]                       # N w between ~2 and ~20 here
+    mean, var = offs[:, heavy].mean(axis=0), offs[:, heavy].var(axis=0, ddof=1)
+    exp_mean, exp_var = n * w[heavy], n * w[heavy] * (1 - w[heavy])
+    assert np.all(np.abs(mean - exp_mean) < 5 * np.sqrt(exp_var / reps))
+    assert np.all(np.abs(var / exp_var - 1) < 0.45) and abs(np.mean(var / exp_var) - 1) < 0.1
+    assert len({tuple(o) for o in offs[:5]}) == 5     # different seeds, different draws
+
+
 def test_ess_bisection_option(pkg, data):
     """BASELINE.json: "adaptive tempering via ESS bisection" (the reference backs off geometrically and stops up to
     30 % short of the crossing).  Each step must land on ESS/N = ess_limit from above, the run must need fewer
