@@ -82,6 +82,20 @@ int smc_set_model_mm(smc_ctx *ctx, const double *t, const double *P_obs, const d
 int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *guess, const double *obs, int n_data,
                               const double *base_params, const int *est_position, int est_sigma, double sigma_fixed,
                               double tf, double rtol, double atol);
+/* User model (the reference's README.md:4 "modify for your problem", i.e. a new
+ * Micmem_likelihood.py): `source` is HIP device code defining, for the state y[n_states] of an ODE,
+ *   __device__ void   smc_user_y0 (const double *theta, const double *cond, double *y);            initial state at t[e][0]
+ *   __device__ void   smc_user_rhs(double t, const double *y, const double *theta, const double *cond, double *dydt);
+ *   __device__ double smc_user_obs(double t, const double *y, const double *theta, const double *cond);   what obs is compared with
+ * (theta: the particle's `dim` values; cond: the n_cond numbers of experiment e).  It is compiled at run time (hiprtc,
+ * gfx950) into a kernel that restates solve_ivp(RK45, t_eval = t[e], rtol, atol) and the Gaussian log-likelihood of
+ * Micmem_likelihood.py:17-33,62-73 with sigma = the last parameter (est_sigma) or sigma_fixed; smc_loglik and
+ * smc_mh_step_* then use it.  t, obs: n_ex x n_t; cond: n_ex x n_cond.  A source that does not compile fails with
+ * hiprtc's log in smc_last_error.  smc_user_model_check only compiles (no GPU needed): 0 ok, 1 compile error (log). */
+#define SMC_USER_MAX_STATES 8
+int smc_set_model_user(smc_ctx *ctx, const char *source, int n_states, const double *t, const double *obs, const double *cond,
+                       int n_ex, int n_t, int n_cond, int est_sigma, double sigma_fixed, double rtol, double atol);
+int smc_user_model_check(const char *source, int n_states, int dim, char *log, int log_cap);
 /* Independent priors, one per parameter: kind[i] in {SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL, SMC_PRIOR_FLAT}; (a,b) =
  * (low,high) or (mu,sigma).  Used by the support mask of cal_prior (Micmem_SMC_main.py:60-90,
  * 224-228) and by smc_sample_prior_device. */

@@ -15,3 +15,4 @@ from .driver import SMCSettings, ess_candidates, ess_search, mvn_transform, prop
 from .engine import HipEngine  # noqa: F401
 from . import methanation  # noqa: F401
 from . import datagen  # noqa: F401
+from . import user_models  # noqa: F401

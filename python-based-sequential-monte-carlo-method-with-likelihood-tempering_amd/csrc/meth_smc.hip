@@ -226,20 +226,31 @@ void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64
                        theta, stride, n, ctx->d_mflows, lk);
 }
 
-void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
-    if (n <= 0) return;
+void launch_generic_propose(smc_ctx *ctx, int64_t n, const MHParams &mh) {
+    ParticleSet &F = ctx->set[SMC_SET_FILT];
+    ParticleSet &P = ctx->set[SMC_SET_PRED];
+    hipLaunchKernelGGL(generic_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
+                       F.theta, F.stride, n, ctx->dim, P.theta, P.stride, ctx->d_p0);
+}
+
+void launch_generic_accept(smc_ctx *ctx, int64_t n, const MHParams &mh, const double *lk2) {
     ParticleSet &F = ctx->set[SMC_SET_FILT];
     ParticleSet &P = ctx->set[SMC_SET_PRED];
     const bool dbg = ctx->debug_capture != 0;
-    hipLaunchKernelGGL(generic_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
-                       F.theta, F.stride, n, ctx->dim, P.theta, P.stride, ctx->d_p0);
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(generic_accept_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, ctx->stream, mh, P.theta,
+                       P.stride, n, ctx->dim, lk2, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac, ctx->d_counters,
+                       dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);
+}
+
+void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
+    if (n <= 0) return;
+    ParticleSet &P = ctx->set[SMC_SET_PRED];
+    launch_generic_propose(ctx, n, mh);
     launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0);
     hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
                        P.theta, P.stride, n, ctx->d_mflows, ctx->d_mlk2);
-    const int64_t g = (n + 255) / 256;
-    hipLaunchKernelGGL(generic_accept_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, ctx->stream, mh, P.theta,
-                       P.stride, n, ctx->dim, ctx->d_mlk2, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac, ctx->d_counters,
-                       dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);
+    launch_generic_accept(ctx, n, mh, ctx->d_mlk2);
 }
 
 }  // namespace smc

@@ -53,6 +53,7 @@ static int fail(smc_ctx *ctx, const char *msg) {
         g_err = msg;
     return 1;
 }
+int smc_fail(smc_ctx *ctx, const char *msg) { return fail(ctx, msg); }
 
 // ---- timing ---------------------------------------------------------------------------------
 namespace smc {
@@ -198,6 +199,7 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_info);
     (void)hipFree(c->d_p0);
     (void)hipFree(c->d_pratio);
+    user_model_release(c);
     (void)hipFree(c->d_mn_thr);
     (void)hipFree(c->d_mn_blk);
     (void)hipFree(c->d_queue);
@@ -448,6 +450,8 @@ int smc_loglik(smc_ctx *c, int set, int64_t *n_failed, int64_t *rk_attempts) {
         ScopedTimer tm(c, SMC_T_LOGLIK);
         if (c->model_kind == 2)
             launch_meth_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk);
+        else if (c->model_kind == 3)
+            launch_user_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk);
         else
             launch_mm_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk, nullptr);
     }
@@ -805,7 +809,7 @@ int smc_mh_step_host_rng(smc_ctx *c, double gamma, double mhstep_ratio, const do
     mh.pratio = c->d_pratio;
     {
         ScopedTimer tm(c, SMC_T_MH);
-        if (c->model_kind == 2) launch_meth_mh(c, n, mh); else launch_mm_mh(c, n, mh);
+        if (c->model_kind == 2) launch_meth_mh(c, n, mh); else if (c->model_kind == 3) launch_user_mh(c, n, mh); else launch_mm_mh(c, n, mh);
     }
     return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
 }
@@ -829,7 +833,7 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
     for (int i = 0; i < c->dim * c->dim; ++i) mh.transform[i] = transform[i];
     {
         ScopedTimer tm(c, SMC_T_MH);
-        if (c->model_kind == 2) launch_meth_mh(c, c->n_local, mh); else launch_mm_mh(c, c->n_local, mh);
+        if (c->model_kind == 2) launch_meth_mh(c, c->n_local, mh); else if (c->model_kind == 3) launch_user_mh(c, c->n_local, mh); else launch_mm_mh(c, c->n_local, mh);
     }
     return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
 }

@@ -9,6 +9,8 @@
 
 #include "../../include/smc_hip.h"
 
+int smc_fail(smc_ctx *ctx, const char *msg);   // records the message (smc_last_error) and returns 1
+
 namespace smc {
 
 constexpr int kWave = 64;            // gfx950 wavefront
@@ -83,7 +85,8 @@ struct smc_ctx {
     uint8_t *r_ac = nullptr;
 
     // model
-    int model_kind = 0;   // 0 none, 1 Michaelis-Menten, 2 methanation
+    int model_kind = 0;   // 0 none, 1 Michaelis-Menten, 2 methanation, 3 user model (hiprtc)
+    void *user = nullptr; // UserModel (user_model.hip)
     smc::MethModel meth{};
     double *d_mcond = nullptr, *d_mguess = nullptr, *d_mobs = nullptr, *d_mflows = nullptr, *d_mlk2 = nullptr;
     int *d_mstatus = nullptr;
@@ -155,6 +158,13 @@ int query_solve_blocks_per_cu();
 // implemented in meth_smc.hip
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);
 void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
+// any dimension: proposal + support mask into the PRED set / d_p0; accept-select from a per-particle lk2 array
+void launch_generic_propose(smc_ctx *ctx, int64_t n, const MHParams &mh);
+void launch_generic_accept(smc_ctx *ctx, int64_t n, const MHParams &mh, const double *lk2);
+// user model (user_model.hip)
+void launch_user_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);
+void launch_user_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
+void user_model_release(smc_ctx *ctx);
 
 struct ScopedTimer {
     smc_ctx *c;

@@ -1,0 +1,372 @@
+// user_model.hip -- SURVEY.md 8(f) N1: the reference is meant to be "modified for your problem" (README.md:4): a user
+// writes Micmem_likelihood.py's three ingredients - the ODE right-hand side (:14-15), the initial state and what is
+// compared with the data (:17-33) - and keeps the drivers.  Here the same three ingredients are given as HIP device
+// functions; they are compiled at run time (hiprtc, gfx950) into the likelihood kernel below and plugged into the
+// on-device loop (propose -> solve -> accept) exactly like the two built-in models.
+//
+// The kernel restates solve_ivp(method="RK45", t_eval=t, rtol, atol) for an NS-dimensional state as SciPy does it
+// (scipy/integrate/_ivp: rk.py rk_step / _step_impl, common.py select_initial_step and RMS norm, ivp.py t_eval
+// dispatch through the quartic dense output) and the Gaussian log-likelihood of Micmem_likelihood.py:62-73.
+// For NS = 1 every operation is in the order of the built-in Michaelis-Menten kernel, so the MM model written as a user
+// model reproduces it (tests/test_gpu_user_model.py); for NS > 1 the stage sums are plain left-to-right sums where
+// NumPy calls BLAS, so agreement with SciPy is at rounding level per step, not bitwise.
+// First version: one thread per particle, experiments in sequence (no lane-level scheduler yet).
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smc_hip.h"
+#include "smc_internal.h"
+
+namespace smc {
+
+static const char *kUserKernelSource = R"SRC(
+// ---- appended by libsmc_hip.so after the user's source -------------------------------------------------------
+#define NS SMC_USER_NS
+namespace smc_user {
+__device__ const double RK_A[6][5] = {
+    {0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+__device__ const double RK_C[6] = {0.0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1.0};
+__device__ const double RK_B[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+__device__ const double RK_E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+__device__ const double RK_P[7][4] = {
+    {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+    {0, 0, 0, 0},
+    {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+    {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+    {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+    {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+    {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+
+__device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
+// common.py:63-65  np.linalg.norm(x) / x.size ** 0.5
+__device__ __forceinline__ double rms(const double *x) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s += x[i] * x[i];
+    return sqrt(s) / sqrt((double)NS);
+}
+
+// one solve_ivp call with t_eval = t[0..n_t); adds (obs - smc_user_obs)^2 over the outputs to *sum_r2.
+// returns 0, or -1 when the step size underflows (the reference's solver raises)
+__device__ int integrate(const double *theta, const double *cond, const double *t_eval, const double *obs, int n_t,
+                         double rtol, double atol, double *sum_r2, unsigned long long *attempts) {
+    const double t0 = t_eval[0], t_bound = t_eval[n_t - 1];
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    double t = t0, y[NS], f[NS], K[7][NS], y_new[NS], f_new[NS], tmp[NS];
+    smc_user_y0(theta, cond, y);
+    smc_user_rhs(t, y, theta, cond, f);
+    double h_abs;
+    {   // common.py select_initial_step, direction +1, order 4, max_step inf
+        const double interval_length = fabs(t_bound - t0);
+        if (interval_length == 0.0) {
+            h_abs = 0.0;
+        } else {
+            double scale[NS], y1[NS], f1[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { scale[i] = atol + fabs(y[i]) * rtol; tmp[i] = y[i] / scale[i]; }
+            const double d0 = rms(tmp);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) tmp[i] = f[i] / scale[i];
+            const double d1 = rms(tmp);
+            double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+            h0 = py_min(h0, interval_length);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) y1[i] = y[i] + h0 * 1.0 * f[i];
+            smc_user_rhs(t0 + h0 * 1.0, y1, theta, cond, f1);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) tmp[i] = (f1[i] - f[i]) / scale[i];
+            const double d2 = rms(tmp) / h0;
+            const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? py_max(1e-6, h0 * 1e-3) : pow(0.01 / py_max(d1, d2), 1.0 / 5);
+            h_abs = py_min(py_min(py_min(100 * h0, h1), interval_length), inf);
+        }
+    }
+    int i_out = 0;
+    for (;;) {
+        if (t == t_bound) {   // base.py:181-187: nothing left to integrate
+            while (i_out < n_t && t_eval[i_out] <= t) {
+                const double r = obs[i_out] - smc_user_obs(t_eval[i_out], y, theta, cond);
+                *sum_r2 += r * r;
+                ++i_out;
+            }
+            return 0;
+        }
+        const double min_step = 10 * fabs(nextafter(t, inf) - t);
+        if (h_abs < min_step) h_abs = min_step;
+        bool accepted = false, rejected = false;
+        double h = 0.0, t_new = t;
+        while (!accepted) {   // rk.py _step_impl
+            if (h_abs < min_step) return -1;
+            h = h_abs;
+            t_new = t + h;
+            if (t_new - t_bound > 0) t_new = t_bound;
+            h = t_new - t;
+            h_abs = fabs(h);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) K[0][i] = f[i];
+#pragma unroll
+            for (int s = 1; s < 6; ++s) {   // rk_step: dy = K[:s].T @ a[:s] * h
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < s; ++j) acc += K[j][i] * RK_A[s][j];
+                    tmp[i] = y[i] + acc * h;
+                }
+                smc_user_rhs(t + RK_C[s] * h, tmp, theta, cond, K[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc += K[j][i] * RK_B[j];
+                y_new[i] = y[i] + h * acc;
+            }
+            smc_user_rhs(t + h, y_new, theta, cond, f_new);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) K[6][i] = f_new[i];
+            ++*attempts;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                double scale = atol + fmax(fabs(y[i]), fabs(y_new[i])) * rtol;
+                if (y[i] != y[i] || y_new[i] != y_new[i]) scale = y[i] + y_new[i];   // np.maximum propagates NaN
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_E[j];
+                tmp[i] = acc * h / scale;
+            }
+            const double error_norm = rms(tmp);
+            if (error_norm < 1) {
+                double factor = (error_norm == 0) ? 10.0 : py_min(10.0, 0.9 * pow(error_norm, -0.2));
+                if (rejected) factor = py_min(1.0, factor);
+                h_abs *= factor;
+                accepted = true;
+            } else {
+                h_abs *= py_max(0.2, 0.9 * pow(error_norm, -0.2));   // NaN error norm: NaN step, fails on the next check
+                rejected = true;
+            }
+        }
+        const double t_old = t;
+        // outputs in (t_old, t_new] and t_eval[0] == t0 on the first step (ivp.py:700-720): quartic dense output
+        int i_new = i_out;
+        while (i_new < n_t && t_eval[i_new] <= t_new) ++i_new;
+        if (i_new > i_out) {
+            double Q[NS][4];
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_P[j][k];
+                    Q[i][k] = acc;
+                }
+            const double hd = t_new - t_old;
+            for (int io = i_out; io < i_new; ++io) {
+                const double x = (t_eval[io] - t_old) / hd;
+                const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+                double yy[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double acc = 0.0;
+                    acc += Q[i][0] * p1;
+                    acc += Q[i][1] * p2;
+                    acc += Q[i][2] * p3;
+                    acc += Q[i][3] * p4;
+                    yy[i] = hd * acc + y[i];
+                }
+                const double r = obs[io] - smc_user_obs(t_eval[io], yy, theta, cond);
+                *sum_r2 += r * r;
+            }
+            i_out = i_new;
+        }
+        t = t_new;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { y[i] = y_new[i]; f[i] = f_new[i]; }
+        if (t - t_bound >= 0) return 0;
+    }
+}
+}  // namespace smc_user
+
+// log-likelihood of Micmem_likelihood.py:62-73 per particle; counters: [0] failed solves, [1] RK45 step attempts
+extern "C" __global__ void __launch_bounds__(256)
+smc_user_loglik_kernel(const double *theta_soa, long long stride, long long n, const unsigned char *p0mask, const double *t,
+                       const double *obs, const double *cond, int n_ex, int n_t, int n_cond, int est_sigma,
+                       double sigma_fixed, double rtol, double atol, double *lk_out, unsigned long long *counters) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (p0mask && p0mask[p] == 0) return;   // proposal reset to the current point: the stored likelihood is used
+    double th[SMC_USER_DIM];
+#pragma unroll
+    for (int c = 0; c < SMC_USER_DIM; ++c) th[c] = theta_soa[c * stride + p];
+    const double sigma = est_sigma ? th[SMC_USER_DIM - 1] : sigma_fixed;
+    if (sigma <= 0.0) {   // Micmem_likelihood.py:53-54
+        lk_out[p] = -__longlong_as_double(0x7ff0000000000000LL);
+        return;
+    }
+    const double s2 = sigma * sigma;
+    const double c0 = (-0.5 * n_t) * log(2.0 * 3.141592653589793 * s2);
+    double lk = 0.0;
+    unsigned long long attempts = 0, failed = 0;
+    for (int e = 0; e < n_ex; ++e) {
+        double sr2 = 0.0;
+        if (smc_user::integrate(th, cond + (long long)e * n_cond, t + (long long)e * n_t, obs + (long long)e * n_t, n_t, rtol,
+                                atol, &sr2, &attempts) != 0)
+            failed = 1;
+        lk += c0 - sr2 / (2.0 * s2);
+    }
+    lk_out[p] = lk;
+    if (failed) atomicAdd(&counters[0], 1ULL);
+    atomicAdd(&counters[1], attempts);
+}
+)SRC";
+
+struct UserModel {
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    double *d_t = nullptr, *d_obs = nullptr, *d_cond = nullptr;
+    int n_ex = 0, n_t = 0, n_cond = 0, n_states = 0, est_sigma = 1;
+    double sigma_fixed = 0, rtol = 1e-3, atol = 1e-6;
+};
+
+static std::string build_source(const char *user_source, int n_states, int dim) {
+    char head[128];
+    snprintf(head, sizeof head, "#define SMC_USER_NS %d\n#define SMC_USER_DIM %d\n", n_states, dim);
+    return std::string(head) + user_source + "\n" + kUserKernelSource;
+}
+
+// compile for gfx950; on failure `log` holds hiprtc's diagnostics
+static bool compile_user(const std::string &src, std::vector<char> &code, std::string &log) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "smc_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+        log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-fno-fast-math"};
+    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    size_t ls = 0;
+    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+        log.resize(ls);
+        (void)hiprtcGetProgramLog(prog, &log[0]);
+    }
+    bool ok = (r == HIPRTC_SUCCESS);
+    if (ok) {
+        size_t cs = 0;
+        ok = hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs > 0;
+        if (ok) {
+            code.resize(cs);
+            ok = hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS;
+        }
+    }
+    (void)hiprtcDestroyProgram(&prog);
+    return ok;
+}
+
+void user_model_release(smc_ctx *c) {
+    UserModel *u = (UserModel *)c->user;
+    if (!u) return;
+    (void)hipFree(u->d_t);
+    (void)hipFree(u->d_obs);
+    (void)hipFree(u->d_cond);
+    if (u->module) (void)hipModuleUnload(u->module);
+    delete u;
+    c->user = nullptr;
+}
+
+static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask, double *lk) {
+    UserModel *u = (UserModel *)c->user;
+    long long stride_ = stride, n_ = n;
+    unsigned long long *counters = (unsigned long long *)c->d_counters;   // SweepCounters: n_failed, rk_attempts first
+    void *args[] = {(void *)&theta, &stride_, &n_, (void *)&p0mask, &u->d_t, &u->d_obs, &u->d_cond, &u->n_ex, &u->n_t,
+                    &u->n_cond, &u->est_sigma, &u->sigma_fixed, &u->rtol, &u->atol, &lk, &counters};
+    ScopedTimer tm(c, SMC_T_SOLVE);
+    (void)hipModuleLaunchKernel(u->fn, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr);
+}
+
+void launch_user_loglik(smc_ctx *c, const double *theta, int64_t stride, int64_t n, double *lk) {
+    if (n > 0) launch_user_kernel(c, theta, stride, n, nullptr, lk);
+}
+
+void launch_user_mh(smc_ctx *c, int64_t n, const MHParams &mh) {
+    if (n <= 0) return;
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    launch_generic_propose(c, n, mh);
+    launch_user_kernel(c, P.theta, P.stride, n, c->d_p0, c->d_mlk2);
+    launch_generic_accept(c, n, mh, c->d_mlk2);
+}
+
+}  // namespace smc
+
+using namespace smc;
+
+extern "C" {
+
+int smc_user_model_check(const char *source, int n_states, int dim, char *log, int log_cap) {
+    if (!source || n_states < 1 || n_states > SMC_USER_MAX_STATES || dim < 1 || dim > SMC_MAX_DIM) return 2;
+    std::vector<char> code;
+    std::string lg;
+    const bool ok = compile_user(build_source(source, n_states, dim), code, lg);
+    if (log && log_cap > 0) {
+        strncpy(log, lg.c_str(), (size_t)log_cap - 1);
+        log[log_cap - 1] = 0;
+    }
+    return ok ? 0 : 1;
+}
+
+int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const double *t, const double *obs, const double *cond,
+                       int n_ex, int n_t, int n_cond, int est_sigma, double sigma_fixed, double rtol, double atol) {
+    if (!c) return smc_fail(nullptr, "NULL context");
+    if (!source) return smc_fail(c, "smc_set_model_user: NULL source");
+    if (n_states < 1 || n_states > SMC_USER_MAX_STATES) return smc_fail(c, "smc_set_model_user: n_states out of range");
+    if (n_ex < 1 || n_t < 1 || n_cond < 0) return smc_fail(c, "smc_set_model_user: bad data shape");
+    if (hipSetDevice(c->device) != hipSuccess) return smc_fail(c, "hipSetDevice failed");
+    std::vector<char> code;
+    std::string lg;
+    if (!compile_user(build_source(source, n_states, c->dim), code, lg)) {
+        std::string msg = "user model does not compile:\n" + lg;
+        if (msg.size() > 3500) msg.resize(3500);
+        return smc_fail(c, msg.c_str());
+    }
+    (void)hipStreamSynchronize(c->stream);
+    user_model_release(c);
+    UserModel *u = new UserModel();
+    c->user = u;
+    if (hipModuleLoadData(&u->module, code.data()) != hipSuccess ||
+        hipModuleGetFunction(&u->fn, u->module, "smc_user_loglik_kernel") != hipSuccess) {
+        user_model_release(c);
+        return smc_fail(c, "smc_set_model_user: loading the compiled module failed");
+    }
+    const size_t nt = (size_t)n_ex * n_t * sizeof(double), nc = (size_t)n_ex * (n_cond > 0 ? n_cond : 1) * sizeof(double);
+    bool ok = hipMalloc(&u->d_t, nt) == hipSuccess && hipMalloc(&u->d_obs, nt) == hipSuccess && hipMalloc(&u->d_cond, nc) == hipSuccess;
+    ok = ok && hipMemcpy(u->d_t, t, nt, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(u->d_obs, obs, nt, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && n_cond > 0) ok = hipMemcpy(u->d_cond, cond, nc, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && !c->d_mlk2) ok = hipMalloc(&c->d_mlk2, (size_t)c->n_local * sizeof(double)) == hipSuccess;
+    if (!ok) {
+        user_model_release(c);
+        return smc_fail(c, "smc_set_model_user: device allocation / upload failed");
+    }
+    u->n_ex = n_ex;
+    u->n_t = n_t;
+    u->n_cond = n_cond;
+    u->n_states = n_states;
+    u->est_sigma = est_sigma;
+    u->sigma_fixed = sigma_fixed;
+    u->rtol = rtol;
+    u->atol = atol;
+    c->model_kind = 3;
+    c->have_model = true;
+    return 0;
+}
+
+}  // extern "C"

@@ -85,6 +85,21 @@ class HipEngine:
                  "smc_set_model_mm")
         self.model = ("mm", t.shape[0], t.shape[1])
 
+    def set_model_user(self, source: str, n_states: int, t, obs, cond=None, est_sigma=True, sigma_fixed=5.0, rtol=1e-3,
+                       atol=1e-6):
+        """A user-written model in place of Micmem_likelihood.py (include/smc_hip.h, smc_set_model_user): `source`
+        defines smc_user_y0 / smc_user_rhs / smc_user_obs as HIP device functions; t, obs: (n_ex, n_t); cond: (n_ex, n_cond)
+        per-experiment numbers (e.g. the initial concentration).  Raises SmcError with the compiler log if the source
+        does not compile."""
+        t = _f64(t)
+        obs = _f64(obs, t.shape)
+        cond = np.zeros((t.shape[0], 0)) if cond is None else _f64(np.asarray(cond).reshape(t.shape[0], -1))
+        cbuf = np.ascontiguousarray(cond if cond.size else np.zeros((t.shape[0], 1)))
+        self._ck(self.L.smc_set_model_user(self.ctx, source.encode(), int(n_states), _dp(t), _dp(obs), _dp(cbuf), t.shape[0],
+                                           t.shape[1], cond.shape[1], int(bool(est_sigma)), float(sigma_fixed), float(rtol),
+                                           float(atol)), "smc_set_model_user")
+        self.model = ("user", t.shape[0], t.shape[1])
+
     def set_model_methanation(self, cond, guess, obs, base_params, est_position, est_sigma=True, sigma_fixed=5.0,
                               tf=75.0, rtol=1e-6, atol=1e-6):
         """cond: dict with Ca_in..Ce_in, T_in, T_jacket, u_in, void, reactorlength (the reference's settings arrays,
