@@ -226,9 +226,33 @@ def _dump(dump_dir, name, arr, rank, world, header=None):
     return path
 
 
+def _save_state(dump_dir, step, rank, world, state):
+    """Next to pred/{step}_p_pred.csv: what the loop needs to go on from there (the reference only writes, it cannot
+    resume: SURVEY.md 2, checkpoint row)."""
+    import json
+    import os
+    suffix = "" if world == 1 else f"_rank{rank}"
+    with open(os.path.join(dump_dir, "pred", f"{step}_state{suffix}.json"), "w") as fh:
+        json.dump(state, fh)
+
+
+def _rng_state_to_json(st):
+    return [st[0], [int(v) for v in st[1]], int(st[2]), int(st[3]), float(st[4])]
+
+
+def _rng_state_from_json(j):
+    return (j[0], np.array(j[1], dtype=np.uint32), j[2], j[3], j[4])
+
+
 def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy", verbose: bool = True,
-            p_pred0=None, seed_device: int | None = None, log=print, dump_dir: str | None = None):
+            p_pred0=None, seed_device: int | None = None, log=print, dump_dir: str | None = None,
+            resume_from: tuple | None = None):
     """Run the tempering loop (main:95-262).  The engine must already hold the model and the prior.
+
+    dump_dir: per-step dumps in the reference's formats plus a small state file per step.
+    resume_from=(dir, step): continue a dumped run after tempering step `step` - particles from pred/{step}_p_pred.csv,
+    likelihoods recomputed, gamma / logZ / random state from pred/{step}_state.json; with rng="device" the continuation
+    is bit-identical to the uninterrupted run (tests/test_gpu_parity.py).
 
     Returns a dict: final particles (this rank's block), lk, schedule records, logZ, counters.
     """
@@ -247,39 +271,57 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "particle_mutation_steps": 0}
 
-    # ---- prior draw (Micmem_settings.py:47,84-87) ----
-    if rng == "numpy":
-        if p_pred0 is None:
-            np.random.seed(s.seed)
-            p_pred0 = sample_prior(s.priors, n)
-        engine.upload_particles(SMC_SET_PRED, np.ascontiguousarray(p_pred0[lo:lo + n_local]))
-        host_rng = None
-    elif rng == "device":
-        seed_device = s.seed if seed_device is None else seed_device
-        if p_pred0 is None:
-            engine.sample_prior_device(seed_device, lo)
-        else:
-            engine.upload_particles(SMC_SET_PRED, np.ascontiguousarray(p_pred0[lo:lo + n_local]))
-        host_rng = np.random.RandomState(seed_device & 0xFFFFFFFF)           # the one scalar draw per step (:156)
-    else:
-        raise ValueError("rng must be 'numpy' or 'device'")
-
     def account(info):
         stats["rk_attempts"] += info["rk_attempts"]
         stats["n_failed"] += info["n_failed"]
 
-    if dump_dir:
+    gamma_old, gamma_new = 0.0, 1.0
+    logZ = 0.0
+    first_step_no = 1
+    if rng not in ("numpy", "device"):
+        raise ValueError("rng must be 'numpy' or 'device'")
+    seed_device = s.seed if seed_device is None else seed_device
+    host_rng = np.random.RandomState(seed_device & 0xFFFFFFFF) if rng == "device" else None   # one scalar draw per step (:156)
+    if resume_from is not None:
+        import json
+        import os
+        rdir, rstep = resume_from
+        suffix = "" if world == 1 else f"_rank{rank}"
+        block = np.loadtxt(os.path.join(rdir, "pred", f"{rstep}_p_pred{suffix}.csv"), delimiter=",", ndmin=2)
+        assert block.shape == (n_local, d), "the dump does not match this engine's block"
+        with open(os.path.join(rdir, "pred", f"{rstep}_state{suffix}.json")) as fh:
+            st = json.load(fh)
+        assert st["rng"] == rng and st["n_particle"] == n
+        engine.upload_particles(SMC_SET_PRED, block)
+        engine.upload_particles(SMC_SET_FILT, block)          # after the commit of a step both sets hold the same rows
+        gamma_old, logZ, first_step_no = st["gamma"], st["logZ"], rstep + 1
+        if rng == "numpy":
+            np.random.set_state(_rng_state_from_json(st["rng_state"]))
+        else:
+            host_rng.set_state(_rng_state_from_json(st["rng_state"]))
+    elif rng == "numpy":                                                      # prior draw (Micmem_settings.py:47,84-87)
+        if p_pred0 is None:
+            np.random.seed(s.seed)
+            p_pred0 = sample_prior(s.priors, n)
+        engine.upload_particles(SMC_SET_PRED, np.ascontiguousarray(p_pred0[lo:lo + n_local]))
+    else:
+        if p_pred0 is None:
+            engine.sample_prior_device(seed_device, lo)
+        else:
+            engine.upload_particles(SMC_SET_PRED, np.ascontiguousarray(p_pred0[lo:lo + n_local]))
+
+    if dump_dir and resume_from is None:
         _dump(dump_dir, "pred/first_p_pred", engine.download_particles(SMC_SET_PRED), rank, world)
     info = engine.loglik(SMC_SET_PRED)                                        # main:98
     account(info)
     if int(comm.allreduce_sum_i64([info["n_failed"]])[0]):
         raise RuntimeError("an RK45 solve failed in the initial sweep (the reference raises here)")
+    if resume_from is not None:
+        engine.upload_lk(SMC_SET_FILT, engine.download_lk(SMC_SET_PRED))
 
-    gamma_old, gamma_new = 0.0, 1.0
     records = []
-    logZ = 0.0
     step = 0
-    for step in range(1, s.itr_max):                                          # :109
+    for step in range(first_step_no, s.itr_max):                                          # :109
         es = ess_search(engine, comm, gamma_old, s)                           # :111-144
         gamma_new, ess, max_lk = es["gamma_new"], es["ess"], es["max_lk"]
         stats["ess_iters"] += es["iters"]
@@ -344,6 +386,9 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         gamma_old = gamma_new
         if dump_dir:                                                          # SMC_methanation_main.py:422
             _dump(dump_dir, f"pred/{step}_p_pred", engine.download_particles(SMC_SET_PRED), rank, world)
+            rst = np.random.get_state() if rng == "numpy" else host_rng.get_state()
+            _save_state(dump_dir, step, rank, world, {"step": step, "gamma": gamma_new, "logZ": logZ, "rng": rng,
+                                                      "n_particle": n, "rng_state": _rng_state_to_json(rst)})
     if gamma_new < 1.0 and verbose and rank == 0:
         log("tempering does't complete: last gamma =", gamma_new)             # :270-271
     engine.synchronize()

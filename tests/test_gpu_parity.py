@@ -404,6 +404,26 @@ def test_full_run_prior_density_ratio_modes(pkg, O, data, mode):
     assert np.abs(o_mask["p_pred"] - o["p_pred"]).max() > 1e-6
 
 
+def test_resume_from_dump_is_bit_identical(pkg, data, tmp_path):
+    """SURVEY.md 8(f) N3 "+ resume from a dump" (the reference only writes its dumps): a run continued from
+    pred/{k}_p_pred.csv + {k}_state.json ends in exactly the particles, schedule and evidence of the uninterrupted
+    run (device RNG: every draw is keyed by seed, particle, step and iteration)."""
+    n = 8192
+    s = pkg.SMCSettings(n_particle=n)
+    with make_engine(pkg, data, n) as eng:
+        full = pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=21, dump_dir=str(tmp_path))
+    k = 3
+    assert full["step"] > k + 2
+    with make_engine(pkg, data, n) as eng:
+        cont = pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=21, resume_from=(str(tmp_path), k))
+    assert cont["step"] == full["step"] and cont["gamma"] == 1.0
+    assert np.array_equal(cont["p_pred"], full["p_pred"]) and np.array_equal(cont["lk"], full["lk"])
+    assert cont["logZ"] == full["logZ"]
+    tail = full["records"][k:]
+    assert [r["gamma_new"] for r in cont["records"]] == [r["gamma_new"] for r in tail]
+    assert [r["n_accept"] for r in cont["records"]] == [r["n_accept"] for r in tail]
+
+
 def test_systematic_resampling_option(pkg, data):
     """BASELINE.json names systematic resampling; the reference only has the residual variant, so the pin is the
     textbook definition in NumPy: offspring_i = #{k : (u + k)/N in (C_{i-1}, C_i]} with C = cumsum(w)."""
