@@ -87,8 +87,7 @@ def bench_methanation(args):
     missing upstream: synthetic conditions (tests/golden/methanation_information.csv), observations = model at
     baseparams + sigma = 5 noise (SMC_methanation_main.py:89-101).  K8 is parity-unpinned."""
     pkg = entry.load_package()
-    entry.load_oracle()
-    from oracle import methanation as M          # settings-layer conversions + synthetic observations only
+    M = pkg.methanation                          # settings-layer conversions (methanation_set_conditon.py as functions)
     n = args.particles_per_gpu if args.particles_per_gpu != 1_000_000 else 1024
     cond = M.load_conditions(os.path.join(ROOT, "tests", "golden", "methanation_information.csv"))
     guess = M.initial_guess(cond)
@@ -97,13 +96,15 @@ def bench_methanation(args):
     priors = {nm: {"dist": "uniform", "low": float(lo[i]), "high": float(hi[i])}
               for nm, i in zip(["Af", "Eaf", "Ar", "Ear", "sigma"], pos)}
     s = pkg.SMCSettings(n_particle=n, priors=priors)
-    p0 = np.array([M.p0_tuple(cond, i, M.BASEPARAMS) for i in range(30)])
+    p0 = M.p0_rows(cond, M.BASEPARAMS)
     flows0, _, _, _ = pkg.methanation.dae_solve_batch(p0, guess)          # synthetic data from the GPU model itself
     np.random.seed(20250205)
     obs = flows0.T + 5.0 * np.random.standard_normal((5, 30))
     eng = pkg.HipEngine(n, 5, device=int(os.environ.get("LOCAL_RANK", "0")))
     eng.set_model_methanation(cond, guess, obs, base, pos)
     eng.set_prior(priors)
+    if args.meth_sweeps > 0:
+        return bench_methanation_sweeps(args, pkg, eng, s, n)
     for i in range(args.warmup):
         pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=900 + i)
     eng.timing_enable(True)
@@ -133,6 +134,49 @@ def bench_methanation(args):
     eng.close()
 
 
+def bench_methanation_sweeps(args, pkg, eng, s, n):
+    """Config 4 at its stated size (1e5 particles = 3e6 DAE solves per sweep) does not finish a whole run inside one
+    GPU call, so this mode times its two building blocks on a prior-drawn population - the hardest one of a run (stiff
+    corners, failed solves): the initial likelihood sweep and `--meth-sweeps` Metropolis sweeps at a small gamma."""
+    eng.sample_prior_device(4242, 0)
+    eng.timing_enable(True)
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    info = eng.loglik(pkg.SMC_SET_PRED)
+    eng.synchronize()
+    t_lk = time.perf_counter() - t0
+    eng.upload_particles(pkg.SMC_SET_FILT, eng.download_particles(pkg.SMC_SET_PRED))
+    eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+    w_cov = s.w_cov()
+    comm = pkg.SingleComm()
+    t0 = time.perf_counter()
+    acc = []
+    for j in range(args.meth_sweeps):
+        cov_m = pkg.proposal_cov(eng, comm, s, w_cov)
+        out = eng.mh_step_device_rng(0.01, 1.0, pkg.mvn_transform(cov_m), 777, j, 0)
+        acc.append(out["accepted_now"])
+        print(f"sweep {j}: {time.perf_counter() - t0:.1f} s", file=sys.stderr, flush=True)
+    eng.synchronize()
+    t_mh = time.perf_counter() - t0
+    tm = eng.timing_get()
+    print(json.dumps({
+        "metric": "particle-mutation-steps/sec", "value": args.meth_sweeps * n / t_mh, "unit": "particle-mutation-steps/s",
+        "n_gpus": 1, "steps": args.meth_sweeps, "warmup": 0, "ms_per_step": 1e3 * t_mh / args.meth_sweeps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "methanation kinetics (30 experiments x 357-state DAE per particle): Metropolis sweeps over a "
+                               "prior-drawn population at gamma = 0.01; one step = one sweep", "particles_per_gpu": n,
+                   "rng": "device Philox4x32-10", "parity": "K8 unpinned (no IDA in the image)"},
+        "initial_likelihood_sweep_s": t_lk, "dae_solves_initial_sweep": n * 30,
+        "dae_solves_per_s": n * 30 / (tm["loglik"]["ms"] * 1e-3),      # from the unmasked initial sweep
+        "accepted_per_sweep": acc, "note": "proposals outside the prior box are not solved (their share is 1 - accept-eligible)",
+        "kernel_ms": tm,
+        "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF, element-layout scans)",
+                     "bound": "fp64-valu (latency-bound scans)", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": None, "traffic": None},
+    }), flush=True)
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,6 +186,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["mm", "methanation"], default="mm",
                     help="mm = BASELINE.json's headline configuration (default); methanation = config 4 (one GPU)")
+    ap.add_argument("--meth-sweeps", type=int, default=0,
+                    help="methanation only: time this many Metropolis sweeps (and the initial likelihood sweep) instead "
+                         "of whole runs - the mode for config 4's full size, --particles-per-gpu 100000")
     args = ap.parse_args()
     if args.workload == "methanation":
         return bench_methanation(args)

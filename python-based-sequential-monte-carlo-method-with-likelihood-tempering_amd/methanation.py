@@ -1,7 +1,7 @@
-"""Host side of the methanation rows built so far (configs 4-5):
-batched DAE residual, rate law and log-likelihood from outlet flows on the GPU, through the C ABI.
-The time integration that would turn these into `my_model` (SMC_methanation/methanation_set_likelihood.py:
-144-277, Assimulo IDA in the reference) is not built yet."""
+"""Host side of the methanation rows (configs 4-5): batched DAE residual, rate law,
+log-likelihood from outlet flows and the DAE time integration (`my_model`, K8) on the GPU through the C ABI, plus the
+settings-layer conversions of methanation_set_conditon.py as functions of a file path (the drop-in module
+dropin/methanation_set_conditon.py keeps the reference's import-time form)."""
 from __future__ import annotations
 
 import numpy as np
@@ -78,3 +78,66 @@ def dae_solve_batch(p0_all, y0_all, tf=75.0, rtol=1e-6, atol=1e-6, h0=1e-5, want
     info = {"steps": int(stats[0]), "rejects": int(stats[1]), "newton_fail": int(stats[2]), "newton_iters": int(stats[3]),
             "kernel_ms": ms.value}
     return flows, status, states, info
+
+
+# ---- settings layer as functions (methanation_set_conditon.py) ---------------------------------------------------
+DATALIST = [0, 2, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 19, 20, 21, 22, 25, 26, 27, 28, 31, 35, 38, 40, 45, 49, 52, 55, 58]  # :48
+EST_PARAMS_LIST = [1, 1, 1, 1, 0, 0, 0, 0, 1]                                                                                 # :14
+BASEPARAMS = np.array([13.04, 52.2e3, 1.147e5, 96.7e3, 23.34, -6, 0.72, -2.51e3])                                             # :55
+SIGMA_TRUE = 5                                                                                                                # :53
+GAS_R = 8.3144589
+TUBE_AREA = np.pi * (0.01 / 2) ** 2
+
+
+def load_conditions(information_csv: str) -> dict:
+    """Inlet conditions of the n_data experiments from the information table (methanation_set_conditon.py:137-214):
+    concentrations from pressure / temperature / inlet flows, Kelvin temperatures, metres, superficial velocity.
+    As in the reference only the first n_data rows of the datastart..datafin slice are converted (:139,188-212)."""
+    import pandas as pd
+    info = pd.read_csv(information_csv).fillna(0).iloc[DATALIST[0]:DATALIST[-1] + 1].values
+    n_data = len(DATALIST)
+    T_in, T_jacket, length = info[:, 7].copy(), info[:, 5].copy(), info[:, 4].copy()
+    P_total, flows, total = info[:, 9], [info[:, k] for k in (10, 11, 12, 14, 15)], info[:, 16]
+    conc = [np.zeros(n_data) for _ in range(5)]
+    void = np.zeros(n_data)
+    for i in range(n_data):
+        T_in[i] = T_in[i] + 273
+        tot = flows[0][i] + flows[1][i] + flows[2][i] + flows[3][i] + flows[4][i]
+        for k in range(5):
+            conc[k][i] = (P_total[i] * 1e6 + 101325) / GAS_R / T_in[i] * flows[k][i] / tot
+        T_jacket[i] = T_jacket[i] + 273
+        length[i] = length[i] / 1000
+        void[i] = info[i, 6]
+    u_in = total * 1.667e-8 / TUBE_AREA * (101325 * T_in) / ((P_total * 1e6 + 101325) * 298)      # :214
+    return dict(Ca_in=conc[0], Cb_in=conc[1], Cc_in=conc[2], Cd_in=conc[3], Ce_in=conc[4], T_in=T_in, T_jacket=T_jacket,
+                u_in=u_in, void=void, reactorlength=length, n_data=n_data)
+
+
+def initial_guess(cond: dict) -> np.ndarray:
+    """The starting profile of every experiment (SMC_methanation_main.py:47-58): inlet values along the bed, 400 K
+    behind the first node."""
+    n_data = cond["n_data"]
+    guess = np.ones((n_data, 7 * NX))
+    for f, key in enumerate(("Ca_in", "Cb_in", "Cc_in", "Cd_in", "Ce_in", "T_in")):
+        guess[:, f * NX:(f + 1) * NX] = np.asarray(cond[key])[:n_data, None]
+    guess[:, 5 * NX + 1:6 * NX] = 400
+    guess[:, 6 * NX:7 * NX] = np.asarray(cond["u_in"])[:n_data, None]
+    return guess
+
+
+def prior_box():
+    """(low_limit, high_limit, est_position) of the uniform priors (methanation_set_conditon.py:22,59-70)."""
+    use = np.append(BASEPARAMS, SIGMA_TRUE)
+    high = use + use * np.array([25, 1, 30, 2, 1, -2, 1, -2, 2])
+    low = use - use * np.array([4, 1, 4, 1, 1, -2, 1, -2, 0.9])
+    return low, high, [i for i, x in enumerate(EST_PARAMS_LIST) if x == 1]
+
+
+def p0_rows(cond: dict, params) -> np.ndarray:
+    """The p0 tuples of my_model for all experiments (methanation_set_likelihood.py:164): (n_data, 18)."""
+    n_data = cond["n_data"]
+    cols = [np.asarray(cond[k], dtype=np.float64)[:n_data] for k in
+            ("Ca_in", "Cb_in", "Cc_in", "Cd_in", "Ce_in", "T_in", "T_jacket", "u_in", "void")]
+    cols.append(np.asarray(cond["reactorlength"], dtype=np.float64)[:n_data] / (NX - 1))
+    pr = np.asarray(params, dtype=np.float64)[:8]
+    return np.column_stack(cols + [np.full(n_data, v) for v in pr])

@@ -61,3 +61,18 @@ def test_prior(M, gold):
     got = M.cal_prior(gold["prior_theta"])
     assert np.array_equal(got, gold["prior_pdf"])
     assert 0 < (got > 0).sum() < len(got)
+
+
+def test_product_settings_functions_equal_oracle(pkg, M):
+    """methanation.load_conditions / initial_guess / prior_box / p0_rows (the product's functional form of
+    methanation_set_conditon.py, used by bench.py and the tools) against the oracle's restatement, itself pinned by
+    the reference's own conversions (tests/golden/methanation_golden.npz)."""
+    import os
+    csv = os.path.join(os.path.dirname(__file__), "golden", "methanation_information.csv")
+    a, b = pkg.methanation.load_conditions(csv), M.load_conditions(csv)
+    for k in b:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert np.array_equal(pkg.methanation.initial_guess(a), M.initial_guess(b))
+    (la, ha, pa), (lb, hb, pb) = pkg.methanation.prior_box(), M.prior_box()
+    assert np.array_equal(la, lb) and np.array_equal(ha, hb) and pa == pb
+    assert np.array_equal(pkg.methanation.p0_rows(a, M.BASEPARAMS), np.array([M.p0_tuple(b, i, M.BASEPARAMS) for i in range(30)]))

@@ -4,8 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import __graft_entry__ as g
 pkg = g.load_package()
-g.load_oracle()
-from oracle import methanation as M
+M = pkg.methanation
 cond = M.load_conditions(os.path.join(g.ROOT, "tests", "golden", "methanation_information.csv"))
 guess = M.initial_guess(cond)
 lo, hi, pos = M.prior_box()
@@ -13,7 +12,7 @@ rs = np.random.RandomState(0)
 for n_part in [int(a) for a in sys.argv[1:]] or [64, 512]:
     prs = np.tile(M.BASEPARAMS, (n_part, 1))
     prs[:, :4] = (lo[pos] + (hi[pos] - lo[pos]) * rs.uniform(0, 1, (n_part, 5)))[:, :4]
-    p0 = np.array([M.p0_tuple(cond, i, pr) for pr in prs for i in range(30)])
+    p0 = np.concatenate([M.p0_rows(cond, pr) for pr in prs])
     y0 = np.array([guess[i] for pr in prs for i in range(30)])
     t0 = time.perf_counter()
     flows, status, _, info = pkg.methanation.dae_solve_batch(p0, y0)
