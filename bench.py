@@ -29,6 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
+# K8: algorithmic FP64 flop per accepted BDF step = 2.25 Newton iterations x (51 residual rows x ~250 +
+# block-tridiagonal solve 51 x 208) + 0.31 factorisations x (51 x (7x7 inverse ~690 + G, S updates ~340 + Jacobian ~600))
+# ~= 2.25 x 23.4e3 + 0.31 x 83e3 (the iteration / factorisation rates are the measured averages of tools/meth_dae_bench.py)
+FLOP_PER_BDF_STEP = 2.25 * 23.4e3 + 0.31 * 83e3
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 flop x 2.4 GHz (datasheet)
 HBM_PEAK_GBPS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic FP64 flop of one particle-mutation-step (DESIGN.md "Kernels"):
@@ -118,6 +122,7 @@ def bench_methanation(args):
     pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)
     sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs) + args.steps
     solves = sweeps * n * 30
+    bdf_steps = sum(o["stats"]["rk_attempts"] for o in outs)     # accepted BDF steps, counted on the device
     print(json.dumps({
         "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -129,7 +134,9 @@ def bench_methanation(args):
         "tempering_steps_per_run": [o["step"] for o in outs], "mutation_sweeps": sweeps - args.steps,
         "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(), "kernel_ms": tm,
         "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF)", "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
-                     "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None},
+                     "achieved": bdf_steps * FLOP_PER_BDF_STEP / (tm["solve"]["ms"] * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": bdf_steps * FLOP_PER_BDF_STEP / (tm["solve"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "algorithmic_flop_per_bdf_step": FLOP_PER_BDF_STEP, "bdf_steps": bdf_steps, "traffic": None},
     }), flush=True)
     eng.close()
 
@@ -171,8 +178,12 @@ def bench_methanation_sweeps(args, pkg, eng, s, n):
         "accepted_per_sweep": acc, "note": "proposals outside the prior box are not solved (their share is 1 - accept-eligible)",
         "kernel_ms": tm,
         "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF, element-layout scans)",
-                     "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)", "achieved": None, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": None, "traffic": None},
+                     "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
+                     "achieved": info["rk_attempts"] * FLOP_PER_BDF_STEP / (tm["loglik"]["ms"] * 1e-3) / 1e12,
+                     "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": info["rk_attempts"] * FLOP_PER_BDF_STEP / (tm["loglik"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "algorithmic_flop_per_bdf_step": FLOP_PER_BDF_STEP, "bdf_steps_initial_sweep": info["rk_attempts"],
+                     "traffic": None},
     }), flush=True)
     eng.close()
 

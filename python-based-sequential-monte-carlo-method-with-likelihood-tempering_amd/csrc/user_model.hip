@@ -10,7 +10,8 @@
 // For NS = 1 every operation is in the order of the built-in Michaelis-Menten kernel, so the MM model written as a user
 // model reproduces it (tests/test_gpu_user_model.py); for NS > 1 the stage sums are plain left-to-right sums where
 // NumPy calls BLAS, so agreement with SciPy is at rounding level per step, not bitwise.
-// First version: one thread per particle, experiments in sequence (no lane-level scheduler yet).
+// Scheduling as in the built-in kernel: (experiment, particle) items, persistent lanes that take the next item from a
+// global counter when their solve ends; a small built-in kernel then sums the items of a particle into its logL.
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
@@ -57,184 +58,248 @@ __device__ __forceinline__ double rms(const double *x) {
     return sqrt(s) / sqrt((double)NS);
 }
 
-// one solve_ivp call with t_eval = t[0..n_t); adds (obs - smc_user_obs)^2 over the outputs to *sum_r2.
-// returns 0, or -1 when the step size underflows (the reference's solver raises)
-__device__ int integrate(const double *theta, const double *cond, const double *t_eval, const double *obs, int n_t,
-                         double rtol, double atol, double *sum_r2, unsigned long long *attempts) {
+// One solve_ivp(RK45, t_eval = t[0..n_t)) call as a resumable state: item_begin sets it up (initial state, first
+// derivative, select_initial_step), every item_attempt is one pass of rk.py's `while not step_accepted` body plus,
+// when the step is accepted, the t_eval outputs it covers.  sr2 accumulates (obs - smc_user_obs)^2.
+struct Item {
+    double t, h_abs, y[NS], f[NS], sr2;
+    int i_out, status;   // status: 0 running, 1 finished, -1 step size underflow (the reference's solver raises)
+    bool rejected;
+};
+
+__device__ __forceinline__ void emit(Item &it, const double *yy, const double *theta, const double *cond, const double *t_eval,
+                                     const double *obs, int io) {
+    const double r = obs[io] - smc_user_obs(t_eval[io], yy, theta, cond);
+    it.sr2 += r * r;
+}
+
+__device__ void item_begin(Item &it, const double *theta, const double *cond, const double *t_eval, const double *obs, int n_t,
+                           double rtol, double atol) {
     const double t0 = t_eval[0], t_bound = t_eval[n_t - 1];
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    double t = t0, y[NS], f[NS], K[7][NS], y_new[NS], f_new[NS], tmp[NS];
-    smc_user_y0(theta, cond, y);
-    smc_user_rhs(t, y, theta, cond, f);
-    double h_abs;
-    {   // common.py select_initial_step, direction +1, order 4, max_step inf
-        const double interval_length = fabs(t_bound - t0);
-        if (interval_length == 0.0) {
-            h_abs = 0.0;
-        } else {
-            double scale[NS], y1[NS], f1[NS];
+    double tmp[NS];
+    it.t = t0;
+    it.sr2 = 0.0;
+    it.i_out = 0;
+    it.status = 0;
+    it.rejected = false;
+    smc_user_y0(theta, cond, it.y);
+    smc_user_rhs(t0, it.y, theta, cond, it.f);
+    // common.py select_initial_step, direction +1, order 4, max_step inf
+    const double interval_length = fabs(t_bound - t0);
+    if (interval_length == 0.0) {
+        it.h_abs = 0.0;
+    } else {
+        double scale[NS], y1[NS], f1[NS];
 #pragma unroll
-            for (int i = 0; i < NS; ++i) { scale[i] = atol + fabs(y[i]) * rtol; tmp[i] = y[i] / scale[i]; }
-            const double d0 = rms(tmp);
+        for (int i = 0; i < NS; ++i) { scale[i] = atol + fabs(it.y[i]) * rtol; tmp[i] = it.y[i] / scale[i]; }
+        const double d0 = rms(tmp);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) tmp[i] = f[i] / scale[i];
-            const double d1 = rms(tmp);
-            double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
-            h0 = py_min(h0, interval_length);
+        for (int i = 0; i < NS; ++i) tmp[i] = it.f[i] / scale[i];
+        const double d1 = rms(tmp);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = py_min(h0, interval_length);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) y1[i] = y[i] + h0 * 1.0 * f[i];
-            smc_user_rhs(t0 + h0 * 1.0, y1, theta, cond, f1);
+        for (int i = 0; i < NS; ++i) y1[i] = it.y[i] + h0 * 1.0 * it.f[i];
+        smc_user_rhs(t0 + h0 * 1.0, y1, theta, cond, f1);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) tmp[i] = (f1[i] - f[i]) / scale[i];
-            const double d2 = rms(tmp) / h0;
-            const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? py_max(1e-6, h0 * 1e-3) : pow(0.01 / py_max(d1, d2), 1.0 / 5);
-            h_abs = py_min(py_min(py_min(100 * h0, h1), interval_length), inf);
-        }
+        for (int i = 0; i < NS; ++i) tmp[i] = (f1[i] - it.f[i]) / scale[i];
+        const double d2 = rms(tmp) / h0;
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? py_max(1e-6, h0 * 1e-3) : pow(0.01 / py_max(d1, d2), 1.0 / 5);
+        it.h_abs = py_min(py_min(py_min(100 * h0, h1), interval_length), inf);
     }
-    int i_out = 0;
-    for (;;) {
-        if (t == t_bound) {   // base.py:181-187: nothing left to integrate
-            while (i_out < n_t && t_eval[i_out] <= t) {
-                const double r = obs[i_out] - smc_user_obs(t_eval[i_out], y, theta, cond);
-                *sum_r2 += r * r;
-                ++i_out;
-            }
-            return 0;
+    if (it.t == t_bound) {   // base.py:181-187: nothing to integrate
+        while (it.i_out < n_t && t_eval[it.i_out] <= it.t) { emit(it, it.y, theta, cond, t_eval, obs, it.i_out); ++it.i_out; }
+        it.status = 1;
+    }
+}
+
+__device__ void item_attempt(Item &it, const double *theta, const double *cond, const double *t_eval, const double *obs,
+                             int n_t, double rtol, double atol) {
+    const double t_bound = t_eval[n_t - 1];
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    const double t = it.t;
+    const double min_step = 10 * fabs(nextafter(t, inf) - t);
+    // rk.py:111-121: clip at the start of a step (a value raised here stays raised for the re-tries of the step)
+    if (!it.rejected && it.h_abs < min_step) it.h_abs = min_step;
+    if (it.h_abs < min_step) { it.status = -1; return; }
+    double K[7][NS], y_new[NS], f_new[NS], tmp[NS];
+    double h = it.h_abs;
+    double t_new = t + h;
+    if (t_new - t_bound > 0) t_new = t_bound;
+    h = t_new - t;
+    it.h_abs = fabs(h);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) K[0][i] = it.f[i];
+#pragma unroll
+    for (int s = 1; s < 6; ++s) {   // rk_step: dy = K[:s].T @ a[:s] * h
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < s; ++j) acc += K[j][i] * RK_A[s][j];
+            tmp[i] = it.y[i] + acc * h;
         }
-        const double min_step = 10 * fabs(nextafter(t, inf) - t);
-        if (h_abs < min_step) h_abs = min_step;
-        bool accepted = false, rejected = false;
-        double h = 0.0, t_new = t;
-        while (!accepted) {   // rk.py _step_impl
-            if (h_abs < min_step) return -1;
-            h = h_abs;
-            t_new = t + h;
-            if (t_new - t_bound > 0) t_new = t_bound;
-            h = t_new - t;
-            h_abs = fabs(h);
+        smc_user_rhs(t + RK_C[s] * h, tmp, theta, cond, K[s]);
+    }
 #pragma unroll
-            for (int i = 0; i < NS; ++i) K[0][i] = f[i];
+    for (int i = 0; i < NS; ++i) {
+        double acc = 0.0;
 #pragma unroll
-            for (int s = 1; s < 6; ++s) {   // rk_step: dy = K[:s].T @ a[:s] * h
+        for (int j = 0; j < 6; ++j) acc += K[j][i] * RK_B[j];
+        y_new[i] = it.y[i] + h * acc;
+    }
+    smc_user_rhs(t + h, y_new, theta, cond, f_new);
 #pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    double acc = 0.0;
+    for (int i = 0; i < NS; ++i) K[6][i] = f_new[i];
 #pragma unroll
-                    for (int j = 0; j < s; ++j) acc += K[j][i] * RK_A[s][j];
-                    tmp[i] = y[i] + acc * h;
-                }
-                smc_user_rhs(t + RK_C[s] * h, tmp, theta, cond, K[s]);
+    for (int i = 0; i < NS; ++i) {
+        double scale = atol + fmax(fabs(it.y[i]), fabs(y_new[i])) * rtol;
+        if (it.y[i] != it.y[i] || y_new[i] != y_new[i]) scale = it.y[i] + y_new[i];   // np.maximum propagates NaN
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_E[j];
+        tmp[i] = acc * h / scale;
+    }
+    const double error_norm = rms(tmp);
+    if (!(error_norm < 1)) {   // rejected (also for a NaN norm: Python's max(0.2, nan) is 0.2)
+        it.h_abs *= py_max(0.2, 0.9 * pow(error_norm, -0.2));
+        it.rejected = true;
+        return;
+    }
+    double factor = (error_norm == 0) ? 10.0 : py_min(10.0, 0.9 * pow(error_norm, -0.2));
+    if (it.rejected) factor = py_min(1.0, factor);
+    it.h_abs *= factor;
+    it.rejected = false;
+    // outputs in (t, t_new] and t_eval[0] == t0 on the first step (ivp.py:700-720): quartic dense output
+    int i_new = it.i_out;
+    while (i_new < n_t && t_eval[i_new] <= t_new) ++i_new;
+    if (i_new > it.i_out) {
+        double Q[NS][4];
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_P[j][k];
+                Q[i][k] = acc;
             }
+        const double hd = t_new - t;
+        for (int io = it.i_out; io < i_new; ++io) {
+            const double x = (t_eval[io] - t) / hd;
+            const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+            double yy[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc += K[j][i] * RK_B[j];
-                y_new[i] = y[i] + h * acc;
+                acc += Q[i][0] * p1;
+                acc += Q[i][1] * p2;
+                acc += Q[i][2] * p3;
+                acc += Q[i][3] * p4;
+                yy[i] = hd * acc + it.y[i];
             }
-            smc_user_rhs(t + h, y_new, theta, cond, f_new);
-#pragma unroll
-            for (int i = 0; i < NS; ++i) K[6][i] = f_new[i];
-            ++*attempts;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                double scale = atol + fmax(fabs(y[i]), fabs(y_new[i])) * rtol;
-                if (y[i] != y[i] || y_new[i] != y_new[i]) scale = y[i] + y_new[i];   // np.maximum propagates NaN
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_E[j];
-                tmp[i] = acc * h / scale;
-            }
-            const double error_norm = rms(tmp);
-            if (error_norm < 1) {
-                double factor = (error_norm == 0) ? 10.0 : py_min(10.0, 0.9 * pow(error_norm, -0.2));
-                if (rejected) factor = py_min(1.0, factor);
-                h_abs *= factor;
-                accepted = true;
-            } else {
-                h_abs *= py_max(0.2, 0.9 * pow(error_norm, -0.2));   // NaN error norm: NaN step, fails on the next check
-                rejected = true;
-            }
+            emit(it, yy, theta, cond, t_eval, obs, io);
         }
-        const double t_old = t;
-        // outputs in (t_old, t_new] and t_eval[0] == t0 on the first step (ivp.py:700-720): quartic dense output
-        int i_new = i_out;
-        while (i_new < n_t && t_eval[i_new] <= t_new) ++i_new;
-        if (i_new > i_out) {
-            double Q[NS][4];
-#pragma unroll
-            for (int i = 0; i < NS; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_P[j][k];
-                    Q[i][k] = acc;
-                }
-            const double hd = t_new - t_old;
-            for (int io = i_out; io < i_new; ++io) {
-                const double x = (t_eval[io] - t_old) / hd;
-                const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-                double yy[NS];
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    double acc = 0.0;
-                    acc += Q[i][0] * p1;
-                    acc += Q[i][1] * p2;
-                    acc += Q[i][2] * p3;
-                    acc += Q[i][3] * p4;
-                    yy[i] = hd * acc + y[i];
-                }
-                const double r = obs[io] - smc_user_obs(t_eval[io], yy, theta, cond);
-                *sum_r2 += r * r;
-            }
-            i_out = i_new;
-        }
-        t = t_new;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) { y[i] = y_new[i]; f[i] = f_new[i]; }
-        if (t - t_bound >= 0) return 0;
+        it.i_out = i_new;
     }
+    it.t = t_new;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { it.y[i] = y_new[i]; it.f[i] = f_new[i]; }
+    if (t_new - t_bound >= 0) it.status = 1;
 }
 }  // namespace smc_user
 
-// log-likelihood of Micmem_likelihood.py:62-73 per particle; counters: [0] failed solves, [1] RK45 step attempts
+// Persistent lanes over the (experiment, particle) items: a lane that finishes its solve takes the next item from a
+// global counter, so the 100-fold spread of step counts over a prior-like population does not idle the wave
+// (the built-in Michaelis-Menten kernel schedules the same way).  item = e * n + p.
+// Outputs per item: the sum of squared residuals and attempts | failed << 30.
 extern "C" __global__ void __launch_bounds__(256)
-smc_user_loglik_kernel(const double *theta_soa, long long stride, long long n, const unsigned char *p0mask, const double *t,
-                       const double *obs, const double *cond, int n_ex, int n_t, int n_cond, int est_sigma,
-                       double sigma_fixed, double rtol, double atol, double *lk_out, unsigned long long *counters) {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    if (p0mask && p0mask[p] == 0) return;   // proposal reset to the current point: the stored likelihood is used
+smc_user_solve_kernel(const double *theta_soa, long long stride, long long n, const unsigned char *p0mask, const double *t,
+                      const double *obs, const double *cond, int n_ex, int n_t, int n_cond, double rtol, double atol,
+                      double *sum_r2, int *info, unsigned long long *queue) {
+    const long long total = n * n_ex;
+    smc_user::Item it;
+    it.status = 1;
     double th[SMC_USER_DIM];
+    bool live = false, exhausted = false;
+    long long item = 0;
+    int e = 0;
+    unsigned attempts = 0;
+    for (long long guard = 0; guard < (1LL << 40); ++guard) {
+        // refill in batches: setting up a solve (two right-hand sides, a pow) with one lane active costs the whole wave
+        // as much as an attempt, so idle lanes wait until 16 of them can start together (or nothing else is running)
+        const int n_idle = __popcll(__ballot(!live && !exhausted)), n_live = __popcll(__ballot(live));
+        const bool refill = n_idle >= 16 || n_live == 0;
+        while (refill && !live && !exhausted) {
+            item = (long long)atomicAdd(queue, 1ULL);
+            if (item >= total) {
+                exhausted = true;
+            } else {
+                const long long p = item % n;
+                e = (int)(item / n);
+                if (!(p0mask && p0mask[p] == 0)) {   // masked proposals are not solved
 #pragma unroll
-    for (int c = 0; c < SMC_USER_DIM; ++c) th[c] = theta_soa[c * stride + p];
-    const double sigma = est_sigma ? th[SMC_USER_DIM - 1] : sigma_fixed;
-    if (sigma <= 0.0) {   // Micmem_likelihood.py:53-54
-        lk_out[p] = -__longlong_as_double(0x7ff0000000000000LL);
-        return;
+                    for (int c = 0; c < SMC_USER_DIM; ++c) th[c] = theta_soa[c * stride + p];
+                    smc_user::item_begin(it, th, cond + (long long)e * n_cond, t + (long long)e * n_t, obs + (long long)e * n_t,
+                                         n_t, rtol, atol);
+                    attempts = 0;
+                    live = true;
+                }
+            }
+        }
+        if (!__any(live)) break;
+        if (live) {
+            if (it.status == 0) {
+                smc_user::item_attempt(it, th, cond + (long long)e * n_cond, t + (long long)e * n_t, obs + (long long)e * n_t, n_t,
+                                       rtol, atol);
+                ++attempts;
+                if (attempts >= 0x3fffffffu) it.status = -1;
+            }
+            if (it.status != 0) {
+                sum_r2[item] = it.sr2;
+                info[item] = (int)(attempts & 0x3fffffffu) | ((it.status < 0) ? (1 << 30) : 0);
+                live = false;
+            }
+        }
     }
-    const double s2 = sigma * sigma;
-    const double c0 = (-0.5 * n_t) * log(2.0 * 3.141592653589793 * s2);
-    double lk = 0.0;
-    unsigned long long attempts = 0, failed = 0;
-    for (int e = 0; e < n_ex; ++e) {
-        double sr2 = 0.0;
-        if (smc_user::integrate(th, cond + (long long)e * n_cond, t + (long long)e * n_t, obs + (long long)e * n_t, n_t, rtol,
-                                atol, &sr2, &attempts) != 0)
-            failed = 1;
-        lk += c0 - sr2 / (2.0 * s2);
-    }
-    lk_out[p] = lk;
-    if (failed) atomicAdd(&counters[0], 1ULL);
-    atomicAdd(&counters[1], attempts);
 }
 )SRC";
+
+// log-likelihood of Micmem_likelihood.py:62-73 per particle from the per-item sums; counters as in the built-in path
+__global__ void __launch_bounds__(256)
+user_finish_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, int dim, const uint8_t *__restrict__ p0mask,
+                   const double *__restrict__ sum_r2, const int *__restrict__ info, int n_ex, int n_t, int est_sigma,
+                   double sigma_fixed, double *__restrict__ lk_out, SweepCounters *__restrict__ counters) {
+    unsigned long long attempts = 0, failed = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const bool masked = p0mask && p0mask[p] == 0;   // proposal reset to the current point: the stored likelihood is used
+        const double sigma = est_sigma ? theta[(int64_t)(dim - 1) * stride + p] : sigma_fixed;
+        if (!masked && sigma <= 0.0) lk_out[p] = -__longlong_as_double(0x7ff0000000000000LL);   // Micmem_likelihood.py:53-54
+        if (!masked && sigma > 0.0) {
+            const double s2 = sigma * sigma;
+            const double c0 = (-0.5 * n_t) * log(2.0 * 3.141592653589793 * s2);
+            double lk = 0.0;
+            unsigned pf = 0;
+            for (int e = 0; e < n_ex; ++e) {
+                lk += c0 - sum_r2[(int64_t)e * n + p] / (2.0 * s2);
+                const int fl = info[(int64_t)e * n + p];
+                attempts += (unsigned)(fl & 0x3fffffff);
+                pf |= (unsigned)(fl >> 30) & 1u;
+            }
+            failed += pf;
+            lk_out[p] = lk;
+        }
+    }
+    if (failed) atomicAdd(&counters->n_failed, failed);
+    if (attempts) atomicAdd(&counters->rk_attempts, attempts);
+}
 
 struct UserModel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
-    double *d_t = nullptr, *d_obs = nullptr, *d_cond = nullptr;
+    double *d_t = nullptr, *d_obs = nullptr, *d_cond = nullptr, *d_sum = nullptr;
+    int *d_info = nullptr;
     int n_ex = 0, n_t = 0, n_cond = 0, n_states = 0, est_sigma = 1;
     double sigma_fixed = 0, rtol = 1e-3, atol = 1e-6;
 };
@@ -278,6 +343,8 @@ void user_model_release(smc_ctx *c) {
     (void)hipFree(u->d_t);
     (void)hipFree(u->d_obs);
     (void)hipFree(u->d_cond);
+    (void)hipFree(u->d_sum);
+    (void)hipFree(u->d_info);
     if (u->module) (void)hipModuleUnload(u->module);
     delete u;
     c->user = nullptr;
@@ -286,11 +353,20 @@ void user_model_release(smc_ctx *c) {
 static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask, double *lk) {
     UserModel *u = (UserModel *)c->user;
     long long stride_ = stride, n_ = n;
-    unsigned long long *counters = (unsigned long long *)c->d_counters;   // SweepCounters: n_failed, rk_attempts first
+    const int64_t total = n * u->n_ex;
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)c->cu_count * 8;
+    if (blocks > cap) blocks = cap;
     void *args[] = {(void *)&theta, &stride_, &n_, (void *)&p0mask, &u->d_t, &u->d_obs, &u->d_cond, &u->n_ex, &u->n_t,
-                    &u->n_cond, &u->est_sigma, &u->sigma_fixed, &u->rtol, &u->atol, &lk, &counters};
-    ScopedTimer tm(c, SMC_T_SOLVE);
-    (void)hipModuleLaunchKernel(u->fn, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr);
+                    &u->n_cond, &u->rtol, &u->atol, &u->d_sum, &u->d_info, &c->d_queue};
+    {
+        ScopedTimer tm(c, SMC_T_SOLVE);
+        (void)hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream);
+        (void)hipModuleLaunchKernel(u->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr);
+    }
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(user_finish_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, c->stream, theta, stride, n,
+                       c->dim, p0mask, u->d_sum, u->d_info, u->n_ex, u->n_t, u->est_sigma, u->sigma_fixed, lk, c->d_counters);
 }
 
 void launch_user_loglik(smc_ctx *c, const double *theta, int64_t stride, int64_t n, double *lk) {
@@ -342,7 +418,7 @@ int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const doubl
     UserModel *u = new UserModel();
     c->user = u;
     if (hipModuleLoadData(&u->module, code.data()) != hipSuccess ||
-        hipModuleGetFunction(&u->fn, u->module, "smc_user_loglik_kernel") != hipSuccess) {
+        hipModuleGetFunction(&u->fn, u->module, "smc_user_solve_kernel") != hipSuccess) {
         user_model_release(c);
         return smc_fail(c, "smc_set_model_user: loading the compiled module failed");
     }
@@ -352,6 +428,8 @@ int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const doubl
          hipMemcpy(u->d_obs, obs, nt, hipMemcpyHostToDevice) == hipSuccess;
     if (ok && n_cond > 0) ok = hipMemcpy(u->d_cond, cond, nc, hipMemcpyHostToDevice) == hipSuccess;
     if (ok && !c->d_mlk2) ok = hipMalloc(&c->d_mlk2, (size_t)c->n_local * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc(&u->d_sum, (size_t)c->n_local * n_ex * sizeof(double)) == hipSuccess &&
+         hipMalloc(&u->d_info, (size_t)c->n_local * n_ex * sizeof(int)) == hipSuccess;
     if (!ok) {
         user_model_release(c);
         return smc_fail(c, "smc_set_model_user: device allocation / upload failed");

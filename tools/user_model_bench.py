@@ -1,0 +1,27 @@
+"""Throughput of the user-model likelihood kernel (hiprtc, N1) against the built-in Michaelis-Menten kernel on the same particles."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as g
+pkg = g.load_package()
+d = np.load(os.path.join(g.ROOT, "tests", "golden", "mm_data.npz"))
+t, P_obs, S0 = d["t"], d["P_obs"], d["S0"]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+rs = np.random.RandomState(0)
+for label, th in (("posterior-like", np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((n, 3)) * np.array([0.025, 0.0295, 0.00094])),
+                  ("prior-like", rs.uniform(0.01, 10, size=(n, 3)))):
+    with pkg.HipEngine(n, 3, device=0) as eng:
+        eng.set_prior(pkg.SMCSettings().priors)
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        for name in ("built-in", "user"):
+            if name == "built-in":
+                eng.set_model_mm(t, P_obs, S0)
+            else:
+                eng.set_model_user(pkg.user_models.MICHAELIS_MENTEN, 1, t, P_obs, cond=np.asarray(S0)[:, None])
+            eng.loglik(pkg.SMC_SET_PRED)
+            eng.synchronize()
+            t0 = time.perf_counter()
+            info = eng.loglik(pkg.SMC_SET_PRED)
+            eng.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"{label:15s} {name:8s}: {dt*1e3:8.2f} ms per sweep of {n} particles ({n/dt:.3g} particles/s, {info['rk_attempts']/dt/1e9:.2f} G attempts/s)", flush=True)
