@@ -62,7 +62,7 @@ struct DaeStats {
     int steps, rejects, newton_fail, nlu, newton_iters;
     int status;  // 0 ok, 1 step-size underflow / attempt budget exhausted, 2 singular block
 #ifdef SMC_METH_PROFILE
-    long long prof[8];  // shader-clock cycles: 0 build+factor, 1 residual, 2 forward, 3 backward, 4 total, 5 change_D, 6 predictor, 7 D update
+    long long prof[12];  // shader-clock cycles: 0 build+factor, 1 residual, 2 forward, 3 backward, 4 total, 5 change_D, 6 predictor, 7 D update
 #endif
 };
 #ifdef SMC_METH_PROFILE

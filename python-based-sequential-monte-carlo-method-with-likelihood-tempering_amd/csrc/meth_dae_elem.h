@@ -357,7 +357,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
     st.status = 0;
 #ifdef SMC_METH_PROFILE
-    for (int q = 0; q < 8; ++q) st.prof[q] = 0;
+    for (int q = 0; q < 12; ++q) st.prof[q] = 0;
     const long long prof_start_ = clock64();
 #endif
     double t = 0.0, h_abs = h0;
@@ -433,6 +433,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
                 dy_norm_old = dy_norm;
             }
         }
+        SMC_PROF_ADD(st, 8);   // factorisation + Newton loop incl. control (slots 0,7,1,2,3 are inside)
         if (!converged && !fresh) {   // stale matrix: same step again with a fresh one
             force_rebuild = true;
             continue;
@@ -463,6 +464,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
             n_equal = 0;
             continue;
         }
+        SMC_PROF_ADD(st, 9);   // error test
         ++n_equal;
         t = t_new;
         ++st.steps;
@@ -495,7 +497,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
                     if (order < kMaxOrder) { const double e = bdf_error_const(order + 1) * dnew2[f] / sc; sp += e * e; }
                 }
         }
-        SMC_PROF_ADD(st, 6);   // D update shares the predictor slot
+        SMC_PROF_ADD(st, 10);  // D update + order-selection norms
         if (!select) continue;
         const double inf = __longlong_as_double(0x7ff0000000000000LL);
         const double em = (order > 1) ? sqrt(allsum_wave(sm) / (6 * kNX)) : inf;

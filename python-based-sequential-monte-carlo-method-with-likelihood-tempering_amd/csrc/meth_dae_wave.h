@@ -241,7 +241,7 @@ __device__ __forceinline__ void dae_wave_integrate(double *sD, int lane, const d
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
     st.status = 0;
 #ifdef SMC_METH_PROFILE
-    for (int q = 0; q < 8; ++q) st.prof[q] = 0;
+    for (int q = 0; q < 12; ++q) st.prof[q] = 0;
     const long long prof_start_ = clock64();
 #endif
     double t = 0.0, h_abs = h0;

@@ -135,7 +135,7 @@ dae_wave_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
 #ifdef SMC_METH_PROFILE
             atomicAdd(&counters[4], (unsigned long long)st.nlu);
-            for (int q = 0; q < 8; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
+            for (int q = 0; q < 12; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
 #endif
         }
         if (y_final && lane < kNX)
@@ -183,7 +183,7 @@ dae_elem_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
 #ifdef SMC_METH_PROFILE
             atomicAdd(&counters[4], (unsigned long long)st.nlu);
-            for (int q = 0; q < 8; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
+            for (int q = 0; q < 12; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
 #endif
         }
         if (y_final && lane < kNX)
@@ -294,11 +294,11 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipMalloc(&dy0, (size_t)n_solves * kNS * 8)); bufs.push_back(dy0);
     MH(hipMalloc(&dfl, (size_t)n_solves * 5 * 8)); bufs.push_back(dfl);
     MH(hipMalloc(&dst, (size_t)n_solves * sizeof(int))); bufs.push_back(dst);
-    MH(hipMalloc(&dcnt, 16 * sizeof(unsigned long long))); bufs.push_back(dcnt);
+    MH(hipMalloc(&dcnt, 24 * sizeof(unsigned long long))); bufs.push_back(dcnt);
     if (y_final) { MH(hipMalloc(&dyf, (size_t)n_solves * kNS * 8)); bufs.push_back(dyf); }
     MH(hipMemcpy(dp, p0_all, (size_t)n_solves * 18 * 8, hipMemcpyHostToDevice));
     MH(hipMemcpy(dy0, y0_all, (size_t)n_solves * kNS * 8, hipMemcpyHostToDevice));
-    MH(hipMemset(dcnt, 0, 16 * sizeof(unsigned long long)));
+    MH(hipMemset(dcnt, 0, 24 * sizeof(unsigned long long)));
     hipEvent_t e0, e1;
     MH(hipEventCreate(&e0));
     MH(hipEventCreate(&e1));
@@ -335,12 +335,12 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     }
 #ifdef SMC_METH_PROFILE
     {
-        unsigned long long h[16];
+        unsigned long long h[24];
         MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
-        static const char *nm[8] = {"build+factor", "residual", "forward", "backward", "total", "change_D", "predict+Dupd", "jac+transpose"};
+        static const char *nm[12] = {"build+factor", "residual", "forward", "backward", "total", "change_D", "predictor", "jac+transpose", "factor+newton", "error test", "Dupd+select", "-"};
         fprintf(stderr, "[meth profile] solves %lld  nlu/solve %.1f  newton/solve %.1f  steps/solve %.1f\n", (long long)n_solves,
                 (double)h[4] / n_solves, (double)h[3] / n_solves, (double)h[0] / n_solves);
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 11; ++q)
             fprintf(stderr, "[meth profile] %-14s %10.0f cycles/solve  (%.1f %% of total)\n", nm[q], (double)h[8 + q] / n_solves,
                     100.0 * h[8 + q] / (double)h[12]);
         fprintf(stderr, "[meth profile] per factorisation %.0f cycles; per newton iteration: residual %.0f forward %.0f backward %.0f\n",
