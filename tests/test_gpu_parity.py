@@ -404,6 +404,57 @@ def test_full_run_prior_density_ratio_modes(pkg, O, data, mode):
     assert np.abs(o_mask["p_pred"] - o["p_pred"]).max() > 1e-6
 
 
+def test_full_size_properties_at_one_million_particles(pkg, O, data):
+    """BASELINE.json configs[1] size (10^6 particles on one GPU), through size-independent properties: the likelihood
+    of a 10^4-particle block tiled 100 times is bit-periodic (no dependence on scheduling or position) and equals the
+    oracle on the block; the fused ESS sums and the two-pass moments equal NumPy's on the downloaded values;
+    residual-systematic offspring sum to N (or N-1), every count lies within 1 of N w_i, the gathered particles are the
+    ancestors in order; one Metropolis sweep keeps every particle either at its old or at its proposed position."""
+    n, blk = 1_000_000, 10_000
+    block = mixed_particles(blk, seed=9)
+    th = np.tile(block, (n // blk, 1))
+    s = pkg.SMCSettings(n_particle=n)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+        assert info["n_failed"] == 0
+        assert np.array_equal(lk.reshape(-1, blk), np.tile(lk[:blk], (n // blk, 1)))
+        ref = O.mm_loglik_batch(block, data)[0]
+        assert relerr(lk[:blk], ref).max() < TOL_LOGL
+        # ESS partial sums for three increments at once, moments
+        max_lk = eng.max_lk_local()
+        assert max_lk == lk.max()
+        gms = [1.0, 0.01, 1e-4]
+        sw, sw2 = eng.ess_partials(max_lk, gms)
+        for k, gm in enumerate(gms):
+            w = np.exp((lk - max_lk) * gm)
+            assert abs(sw[k] / w.sum() - 1) < 1e-12 and abs(sw2[k] / (w * w).sum() - 1) < 1e-12
+        # resampling at an increment found by the reference's back-off
+        es = pkg.ess_search(eng, pkg.SingleComm(), 0.0, s)
+        out = pkg.resample(eng, pkg.SingleComm(), es, 0.61, s, True)
+        off = eng.download_offspring()
+        w = np.exp((lk - es["max_lk"]) * es["gm"])
+        w = w / w.sum()
+        assert out["n_offspring"] in (n - 1, n) and off.sum() == out["n_offspring"]
+        assert np.all(off >= np.floor(n * w * (1 - 1e-12))) and np.all(np.abs(off - n * w) < 1.0 + 1e-6)
+        anc = eng.download_particles(pkg.SMC_SET_FILT)
+        src = np.repeat(np.arange(n), off)
+        assert np.array_equal(anc[:len(src)], th[src])
+        mean = eng.moment_sums_local() / n
+        assert np.allclose(mean, anc.mean(axis=0), rtol=1e-12, atol=0)
+        cen = eng.moment_centered_local(mean) / n
+        assert np.allclose(cen, np.cov(anc.T, bias=True), rtol=1e-9, atol=0)
+        # one device-RNG Metropolis sweep
+        eng.set_debug_capture(True)
+        cov_m = pkg.proposal_cov(eng, pkg.SingleComm(), s, s.w_cov())
+        mh = eng.mh_step_device_rng(es["gamma_new"], 1.0, pkg.mvn_transform(cov_m), 5, 0, 0)
+        prop, lk2, p0, r = eng.download_debug_proposals()
+        after = eng.download_particles(pkg.SMC_SET_FILT)
+        assert mh["accepted_now"] == int(r.sum()) and 0 < mh["accepted_now"] < n
+        assert np.array_equal(after, np.where(r[:, None] == 1, prop, anc))
+
+
 def test_resume_from_dump_is_bit_identical(pkg, data, tmp_path):
     """SURVEY.md 8(f) N3 "+ resume from a dump" (the reference only writes its dumps): a run continued from
     pred/{k}_p_pred.csv + {k}_state.json ends in exactly the particles, schedule and evidence of the uninterrupted
