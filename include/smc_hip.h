@@ -205,6 +205,11 @@ int smc_comm_allgather_f64(smc_ctx *ctx, const double *in, int n, double *out /*
 int smc_comm_allgather_i64(smc_ctx *ctx, const int64_t *in, int n, int64_t *out /* world*n */);
 int smc_comm_barrier(smc_ctx *ctx);
 
+/* One-rank rehearsal of the particle exchange with real RCCL calls: rows [row, row+cnt) of the PRED set go through
+ * the send staging, an ncclSend/ncclRecv pair addressed to this rank itself and the receive staging into rows
+ * [dst_row, dst_row+cnt) of the FILT set (theta and lk) - step 3 of smc_resample_phase3 for a self-addressed block.
+ * Needs a communicator (smc_comm_init with SMC_FORCE_RCCL=1 on one rank). */
+int smc_debug_rccl_self_exchange(smc_ctx *ctx, int64_t row, int64_t cnt, int64_t dst_row);
 /* Loopback rehearsal of the multi-rank path on ONE device: `peers` are the `world` contexts of one process
  * (peers[rank] == ctx), typically one host thread per rank.  smc_resample_phase3 then only packs (gathers own
  * slots, stages remote ones, synchronises its stream); after a barrier between the threads every rank calls

@@ -80,6 +80,7 @@ SIGNATURES = {
     "smc_comm_allgather_f64": (cint, [c_ctx, c_dp, cint, c_dp]),
     "smc_comm_allgather_i64": (cint, [c_ctx, c_i64p, cint, c_i64p]),
     "smc_comm_barrier": (cint, [c_ctx]),
+    "smc_debug_rccl_self_exchange": (cint, [c_ctx, i64, i64, i64]),
     "smc_debug_set_local_peers": (cint, [c_ctx, ctypes.POINTER(c_ctx), cint, cint]),
     "smc_resample_phase3_pull": (cint, [c_ctx]),
     "smc_timing_enable": (cint, [c_ctx, cint]),

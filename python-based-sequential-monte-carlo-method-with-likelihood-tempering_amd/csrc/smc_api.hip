@@ -596,6 +596,79 @@ int smc_download_offspring(smc_ctx *c, int64_t *p_is, int64_t n) {
 static inline int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 static inline int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
 
+// Particle blocks between ranks: per peer q one ncclSend of send_cnt[q] particles ([component][cnt] layout, d+1
+// components, at d_sendbuf + send_off[q]*(d+1)) and one ncclRecv of recv_cnt[q] particles into the receive staging,
+// all in one group on the context's stream; the received blocks are then spread over the FILT SoA rows starting at
+// recv_row[q].  Entries with a zero count are skipped (a rank may list itself: RCCL copies locally).
+static int rccl_exchange_blocks(smc_ctx *c, const std::vector<int64_t> &send_off, const std::vector<int64_t> &send_cnt,
+                                const std::vector<int64_t> &recv_off, const std::vector<int64_t> &recv_cnt,
+                                const std::vector<int64_t> &recv_row, int64_t recv_total) {
+    const int W = (int)send_cnt.size(), d = c->dim;
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    ncclComm_t comm = (ncclComm_t)c->nccl_comm;
+    if (!comm) return fail(c, "smc_comm_init has not been called");
+    if (recv_total > c->recvbuf_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_recvbuf);
+        c->d_recvbuf = nullptr;
+        c->recvbuf_cap = 0;
+        HIPC(c, hipMalloc(&c->d_recvbuf, (size_t)recv_total * (d + 1) * sizeof(double)));
+        c->recvbuf_cap = recv_total;
+    }
+    NCCLC(c, ncclGroupStart());
+    for (int q = 0; q < W; ++q) {
+        if (send_cnt[q] > 0)
+            NCCLC(c, ncclSend(c->d_sendbuf + (size_t)send_off[q] * (d + 1), (size_t)send_cnt[q] * (d + 1), ncclDouble, q, comm,
+                              c->stream));
+        if (recv_cnt[q] > 0)
+            NCCLC(c, ncclRecv(c->d_recvbuf + (size_t)recv_off[q] * (d + 1), (size_t)recv_cnt[q] * (d + 1), ncclDouble, q, comm,
+                              c->stream));
+    }
+    NCCLC(c, ncclGroupEnd());
+    for (int q = 0; q < W; ++q) {
+        if (recv_cnt[q] == 0) continue;
+        const double *blk = c->d_recvbuf + (size_t)recv_off[q] * (d + 1);
+        const int64_t cnt = recv_cnt[q], off = recv_row[q];
+        for (int k = 0; k < d; ++k)
+            HIPC(c, hipMemcpyAsync(F.theta + (size_t)k * F.stride + off, blk + (size_t)k * cnt, (size_t)cnt * sizeof(double),
+                                   hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(F.lk + off, blk + (size_t)d * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice,
+                               c->stream));
+    }
+    return 0;
+}
+
+// Rehearsal of the exchange on ONE rank: particles [row, row+cnt) of the PRED set travel through d_sendbuf, an RCCL
+// send/recv pair addressed to this rank itself and the receive staging into rows [dst_row, dst_row+cnt) of the FILT set
+// - the code path of smc_resample_phase3's step 3 with real RCCL calls (needs a communicator: SMC_FORCE_RCCL=1).
+int smc_debug_rccl_self_exchange(smc_ctx *c, int64_t row, int64_t cnt, int64_t dst_row) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (row < 0 || cnt < 1 || row + cnt > c->n_local || dst_row < 0 || dst_row + cnt > c->n_local) return fail(c, "bad row range");
+    HIPC(c, hipSetDevice(c->device));
+    const int d = c->dim;
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    if (cnt > c->sendbuf_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_sendbuf);
+        c->d_sendbuf = nullptr;
+        c->sendbuf_cap = 0;
+        HIPC(c, hipMalloc(&c->d_sendbuf, (size_t)cnt * (d + 1) * sizeof(double)));
+        c->sendbuf_cap = cnt;
+    }
+    for (int k = 0; k < d; ++k)
+        HIPC(c, hipMemcpyAsync(c->d_sendbuf + (size_t)k * cnt, P.theta + (size_t)k * P.stride + row, (size_t)cnt * sizeof(double),
+                               hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipMemcpyAsync(c->d_sendbuf + (size_t)d * cnt, P.lk + row, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice,
+                           c->stream));
+    std::vector<int64_t> so(c->world, 0), sc(c->world, 0), ro(c->world, 0), rc(c->world, 0), rr(c->world, 0);
+    sc[c->rank] = cnt;
+    rc[c->rank] = cnt;
+    rr[c->rank] = dst_row;
+    if (rccl_exchange_blocks(c, so, sc, ro, rc, rr, cnt)) return 1;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *offspring_all, int first_step) {
     if (!c) return fail(nullptr, "NULL context");
     HIPC(c, hipSetDevice(c->device));
@@ -664,7 +737,6 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
     // 3. exchange: ONE contiguous send and ONE contiguous recv per peer ([component][cnt] blocks), then the
     //    received blocks are spread over the SoA rows by device-to-device row copies on the same stream
     if (W > 1) {
-        ncclComm_t comm = (ncclComm_t)c->nccl_comm;
         std::vector<int64_t> recv_off(W, 0), recv_cnt(W, 0), recv_row(W, 0);
         int64_t roff = 0;
         for (int q = 0; q < W; ++q) {
@@ -676,35 +748,7 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
             recv_row[q] = lo - R * nl;
             roff += hi - lo;
         }
-        if (roff > c->recvbuf_cap) {
-            HIPC(c, hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_recvbuf);
-            c->d_recvbuf = nullptr;
-            c->recvbuf_cap = 0;
-            HIPC(c, hipMalloc(&c->d_recvbuf, (size_t)roff * (d + 1) * sizeof(double)));
-            c->recvbuf_cap = roff;
-        }
-        NCCLC(c, ncclGroupStart());
-        for (int q = 0; q < W; ++q) {
-            if (q == R) continue;
-            if (send_cnt[q] > 0)
-                NCCLC(c, ncclSend(c->d_sendbuf + (size_t)send_off[q] * (d + 1), (size_t)send_cnt[q] * (d + 1), ncclDouble, q,
-                                  comm, c->stream));
-            if (recv_cnt[q] > 0)
-                NCCLC(c, ncclRecv(c->d_recvbuf + (size_t)recv_off[q] * (d + 1), (size_t)recv_cnt[q] * (d + 1), ncclDouble, q,
-                                  comm, c->stream));
-        }
-        NCCLC(c, ncclGroupEnd());
-        for (int q = 0; q < W; ++q) {
-            if (recv_cnt[q] == 0) continue;
-            const double *blk = c->d_recvbuf + (size_t)recv_off[q] * (d + 1);
-            const int64_t cnt = recv_cnt[q], off = recv_row[q];
-            for (int k = 0; k < d; ++k)
-                HIPC(c, hipMemcpyAsync(F.theta + (size_t)k * F.stride + off, blk + (size_t)k * cnt, (size_t)cnt * sizeof(double),
-                                       hipMemcpyDeviceToDevice, c->stream));
-            HIPC(c, hipMemcpyAsync(F.lk + off, blk + (size_t)d * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice,
-                                   c->stream));
-        }
+        return rccl_exchange_blocks(c, send_off, send_cnt, recv_off, recv_cnt, recv_row, roff);
     }
     return 0;
 }

@@ -305,6 +305,9 @@ class HipEngine:
                                                      r.ctypes.data_as(B.c_u8p), n), "smc_download_debug_proposals")
         return aos, lk2, p0, r
 
+    def debug_rccl_self_exchange(self, row, cnt, dst_row):
+        self._ck(self.L.smc_debug_rccl_self_exchange(self.ctx, int(row), int(cnt), int(dst_row)), "smc_debug_rccl_self_exchange")
+
     # ---- collectives (RCCL) --------------------------------------------------------------------
     @staticmethod
     def comm_get_unique_id() -> bytes:

@@ -626,6 +626,19 @@ def test_rccl_call_sequence_single_rank(pkg, data, golden_run, monkeypatch):
         assert np.array_equal(comm.allgather([1.0, 2.0]), [[1.0, 2.0]])
         assert np.array_equal(comm.allgather_i64([9]), [[9]])
         comm.barrier()
+        # the particle exchange of smc_resample_phase3 with real ncclSend / ncclRecv, addressed to this rank itself
+        th = mixed_particles(1000, seed=4)
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        eng.upload_lk(pkg.SMC_SET_PRED, np.arange(1000.0))
+        eng.upload_particles(pkg.SMC_SET_FILT, np.zeros((1000, 3)))
+        eng.upload_lk(pkg.SMC_SET_FILT, np.zeros(1000))
+        eng.debug_rccl_self_exchange(100, 300, 650)
+        eng.debug_rccl_self_exchange(0, 7, 3)                      # a second, smaller block reuses the staging buffers
+        f, flk = eng.download_particles(pkg.SMC_SET_FILT), eng.download_lk(pkg.SMC_SET_FILT)
+        expect, elk = np.zeros((1000, 3)), np.zeros(1000)
+        expect[650:950], elk[650:950] = th[100:400], np.arange(100.0, 400.0)
+        expect[3:10], elk[3:10] = th[0:7], np.arange(0.0, 7.0)
+        assert np.array_equal(f, expect) and np.array_equal(flk, elk)
         out = pkg.run_smc(eng, pkg.SMCSettings(), comm=comm, rng="numpy", verbose=False)
     assert np.array_equal([r["gamma_new"] for r in out["records"]], g["sched_gamma"])
     assert np.array_equal([r["n_accept"] for r in out["records"]], g["sched_accept"])
