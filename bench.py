@@ -85,6 +85,21 @@ def cpu_baseline(sample_seconds_target=15.0):
             "ess_iters_per_s_n1e6_1core": 1.0 / dt_e}
 
 
+def make_comm(pkg, eng, rank, world):
+    """SingleComm, or the engine's RCCL communicator (torch.distributed/gloo only carries RCCL's 128-byte id)."""
+    if world == 1:
+        return pkg.SingleComm()
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    def bootstrap(uid):
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    return pkg.RcclComm(eng, rank, world, bootstrap)
+
+
 def bench_methanation(args):
     """Config 4 (BASELINE.json configs[3]): methanation kinetics, 30 experiments per particle, 357-state DAE per
     experiment.  One step = one complete adaptive-tempering SMC run on one GPU.  The reference's inlet table is
@@ -93,38 +108,46 @@ def bench_methanation(args):
     pkg = entry.load_package()
     M = pkg.methanation                          # settings-layer conversions (methanation_set_conditon.py as functions)
     n = args.particles_per_gpu if args.particles_per_gpu != 1_000_000 else 1024
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))   # config 5: particle-sharded
     cond = M.load_conditions(os.path.join(ROOT, "tests", "golden", "methanation_information.csv"))
     guess = M.initial_guess(cond)
     lo, hi, pos = M.prior_box()
     base = np.append(M.BASEPARAMS, M.SIGMA_TRUE)
     priors = {nm: {"dist": "uniform", "low": float(lo[i]), "high": float(hi[i])}
               for nm, i in zip(["Af", "Eaf", "Ar", "Ear", "sigma"], pos)}
-    s = pkg.SMCSettings(n_particle=n, priors=priors)
+    s = pkg.SMCSettings(n_particle=n * world, priors=priors)
     p0 = M.p0_rows(cond, M.BASEPARAMS)
-    flows0, _, _, _ = pkg.methanation.dae_solve_batch(p0, guess)          # synthetic data from the GPU model itself
+    flows0, _, _, _ = pkg.methanation.dae_solve_batch(p0, guess, device=int(os.environ.get("LOCAL_RANK", "0")))   # synthetic data
     np.random.seed(20250205)
     obs = flows0.T + 5.0 * np.random.standard_normal((5, 30))
-    eng = pkg.HipEngine(n, 5, device=int(os.environ.get("LOCAL_RANK", "0")))
+    eng = pkg.HipEngine(n, 5, device=int(os.environ.get("LOCAL_RANK", "0")), n_global=n * world)
     eng.set_model_methanation(cond, guess, obs, base, pos)
     eng.set_prior(priors)
     if args.meth_sweeps > 0:
         return bench_methanation_sweeps(args, pkg, eng, s, n)
+    comm = make_comm(pkg, eng, rank, world)
     for i in range(args.warmup):
-        pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=900 + i)
+        pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=900 + i)
     eng.timing_enable(True)
     eng.timing_reset()
+    comm.barrier()
     eng.synchronize()
     t0 = time.perf_counter()
-    outs = [pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=1000 + i) for i in range(args.steps)]
+    outs = [pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=1000 + i) for i in range(args.steps)]
+    comm.barrier()
     eng.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = float(comm.allreduce_max([time.perf_counter() - t0])[0])
     tm = eng.timing_get()
+    if rank != 0:
+        comm.barrier()
+        eng.close()
+        return
     pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)
     sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs) + args.steps
     solves = sweeps * n * 30
     bdf_steps = sum(o["stats"]["rk_attempts"] for o in outs)     # accepted BDF steps, counted on the device
     print(json.dumps({
-        "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s", "n_gpus": 1,
+        "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "methanation kinetics (30 experiments x 357-state DAE per particle), adaptive tempering, "
@@ -138,6 +161,7 @@ def bench_methanation(args):
                      "unit": "TFLOP/s", "frac": bdf_steps * FLOP_PER_BDF_STEP / (tm["solve"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "algorithmic_flop_per_bdf_step": FLOP_PER_BDF_STEP, "bdf_steps": bdf_steps, "traffic": None},
     }), flush=True)
+    comm.barrier()
     eng.close()
 
 
@@ -223,18 +247,7 @@ def main():
     eng = pkg.HipEngine(n_local, 3, device=dev, n_global=n_global)
     eng.set_model_mm(t, P_obs, S0)
     eng.set_prior(s.priors)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # bootstrap channel only
-
-        def bootstrap(uid):
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        comm = pkg.RcclComm(eng, rank, world, bootstrap)
-    else:
-        comm = pkg.SingleComm()
+    comm = make_comm(pkg, eng, rank, world)
 
     def one_run(i):
         return pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=1000 + i)
