@@ -29,10 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
 
-# K8: algorithmic FP64 flop per accepted BDF step = 2.25 Newton iterations x (51 residual rows x ~250 +
-# block-tridiagonal solve 51 x 208) + 0.31 factorisations x (51 x (7x7 inverse ~690 + G, S updates ~340 + Jacobian ~600))
-# ~= 2.25 x 23.4e3 + 0.31 x 83e3 (the iteration / factorisation rates are the measured averages of tools/meth_dae_bench.py)
-FLOP_PER_BDF_STEP = 2.25 * 23.4e3 + 0.31 * 83e3
+# K8: algorithmic FP64 flop = factorisations x 1.1e5 (block-tridiagonal LU, 51 block rows of
+# 7x7) + Newton iterations x (1.5e4 block solve + 2e4 residual evaluation); all counts measured on the device
+FLOP_PER_FACTORISATION, FLOP_PER_NEWTON_ITERATION = 1.1e5, 1.5e4 + 2.0e4
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 FP64 FMA lanes x 2 flop x 2.4 GHz (datasheet)
 HBM_PEAK_GBPS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic FP64 flop of one particle-mutation-step (DESIGN.md "Kernels"):
@@ -145,7 +144,8 @@ def bench_methanation(args):
     pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)
     sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs) + args.steps
     solves = sweeps * n * 30
-    bdf_steps = sum(o["stats"]["rk_attempts"] for o in outs)     # accepted BDF steps, counted on the device
+    k8 = {k: sum(o["stats"].get(k, 0) for o in outs) for k in ("bdf_steps", "newton_iters", "factorisations", "failed_solves")}
+    k8_flop = k8["factorisations"] * FLOP_PER_FACTORISATION + k8["newton_iters"] * FLOP_PER_NEWTON_ITERATION
     print(json.dumps({
         "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -157,9 +157,10 @@ def bench_methanation(args):
         "tempering_steps_per_run": [o["step"] for o in outs], "mutation_sweeps": sweeps - args.steps,
         "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(), "kernel_ms": tm,
         "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF)", "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
-                     "achieved": bdf_steps * FLOP_PER_BDF_STEP / (tm["solve"]["ms"] * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": bdf_steps * FLOP_PER_BDF_STEP / (tm["solve"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                     "algorithmic_flop_per_bdf_step": FLOP_PER_BDF_STEP, "bdf_steps": bdf_steps, "traffic": None},
+                     "achieved": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "device_counts": k8, "flop_per_factorisation": FLOP_PER_FACTORISATION,
+                     "flop_per_newton_iteration": FLOP_PER_NEWTON_ITERATION, "traffic": None},
     }), flush=True)
     comm.barrier()
     eng.close()
@@ -176,6 +177,8 @@ def bench_methanation_sweeps(args, pkg, eng, s, n):
     info = eng.loglik(pkg.SMC_SET_PRED)
     eng.synchronize()
     t_lk = time.perf_counter() - t0
+    k8 = eng.meth_sweep_counters()
+    k8_flop = k8["factorisations"] * FLOP_PER_FACTORISATION + k8["newton_iters"] * FLOP_PER_NEWTON_ITERATION
     eng.upload_particles(pkg.SMC_SET_FILT, eng.download_particles(pkg.SMC_SET_PRED))
     eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
     w_cov = s.w_cov()
@@ -203,11 +206,11 @@ def bench_methanation_sweeps(args, pkg, eng, s, n):
         "kernel_ms": tm,
         "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF, element-layout scans)",
                      "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
-                     "achieved": info["rk_attempts"] * FLOP_PER_BDF_STEP / (tm["loglik"]["ms"] * 1e-3) / 1e12,
+                     "achieved": k8_flop / (tm["loglik"]["ms"] * 1e-3) / 1e12,
                      "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": info["rk_attempts"] * FLOP_PER_BDF_STEP / (tm["loglik"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                     "algorithmic_flop_per_bdf_step": FLOP_PER_BDF_STEP, "bdf_steps_initial_sweep": info["rk_attempts"],
-                     "traffic": None},
+                     "frac": k8_flop / (tm["loglik"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "device_counts_initial_sweep": k8, "flop_per_factorisation": FLOP_PER_FACTORISATION,
+                     "flop_per_newton_iteration": FLOP_PER_NEWTON_ITERATION, "traffic": None},
     }), flush=True)
     eng.close()
 

@@ -96,6 +96,9 @@ int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *gu
 int smc_set_model_user(smc_ctx *ctx, const char *source, int n_states, const double *t, const double *obs, const double *cond,
                        int n_ex, int n_t, int n_cond, int est_sigma, double sigma_fixed, double rtol, double atol);
 int smc_user_model_check(const char *source, int n_states, int dim, char *log, int log_cap);
+/* Methanation model: device-counted work of the LAST smc_loglik / smc_mh_step_* call (the counts the K8
+ * roofline is built from): out = {accepted BDF steps, Newton iterations, Jacobian factorisations, failed solves}. */
+int smc_meth_sweep_counters(smc_ctx *ctx, int64_t out[4]);
 /* Independent priors, one per parameter: kind[i] in {SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL, SMC_PRIOR_FLAT}; (a,b) =
  * (low,high) or (mu,sigma).  Used by the support mask of cal_prior (Micmem_SMC_main.py:60-90,
  * 224-228) and by smc_sample_prior_device. */

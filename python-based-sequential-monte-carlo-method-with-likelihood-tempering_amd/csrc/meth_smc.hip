@@ -71,6 +71,9 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
             }
             status[w] = st.status;
             atomicAdd(&counters->rk_attempts, (unsigned long long)st.steps);
+            atomicAdd(&counters->newton_iters, (unsigned long long)st.newton_iters);
+            atomicAdd(&counters->factorisations, (unsigned long long)st.nlu);
+            if (st.status != 0) atomicAdd(&counters->failed_solves, 1ULL);
         }
     }
 }

@@ -334,6 +334,15 @@ int smc_set_prior_mode(smc_ctx *c, int mode) {
     return 0;
 }
 
+int smc_meth_sweep_counters(smc_ctx *c, int64_t out[4]) {
+    if (!c) return fail(nullptr, "NULL context");
+    out[0] = (int64_t)c->h_counters->rk_attempts;
+    out[1] = (int64_t)c->h_counters->newton_iters;
+    out[2] = (int64_t)c->h_counters->factorisations;
+    out[3] = (int64_t)c->h_counters->failed_solves;
+    return 0;
+}
+
 int smc_set_resampling(smc_ctx *c, int scheme) {
     if (!c) return fail(nullptr, "NULL context");
     if (scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC && scheme != SMC_RESAMPLE_SYSTEMATIC && scheme != SMC_RESAMPLE_MULTINOMIAL)

@@ -64,6 +64,7 @@ struct MHParams {    // passed by value to the fused MH kernel
 
 struct SweepCounters {  // device-side integer counters (order-independent atomics)
     unsigned long long n_failed, rk_attempts, accepted_now, accepted_ever;
+    unsigned long long newton_iters, factorisations, failed_solves;   // K8 only (methanation)
 };
 
 struct EventPair {

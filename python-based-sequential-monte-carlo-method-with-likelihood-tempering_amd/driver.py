@@ -271,9 +271,14 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "particle_mutation_steps": 0}
 
+    meth = getattr(engine, "model", ("",))[0] == "methanation"
+
     def account(info):
         stats["rk_attempts"] += info["rk_attempts"]
         stats["n_failed"] += info["n_failed"]
+        if meth:                                   # K8 work counters of the sweep just done
+            for k, v in engine.meth_sweep_counters().items():
+                stats[k] = stats.get(k, 0) + v
 
     gamma_old, gamma_new = 0.0, 1.0
     logZ = 0.0

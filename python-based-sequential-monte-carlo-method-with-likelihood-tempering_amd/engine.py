@@ -145,6 +145,12 @@ class HipEngine:
         b = np.array(b, dtype=np.float64)
         self._ck(self.L.smc_set_prior(self.ctx, k.ctypes.data_as(B.c_ip), _dp(a), _dp(b), len(kinds)), "smc_set_prior")
 
+    def meth_sweep_counters(self):
+        """Device-counted work of the last methanation sweep: BDF steps, Newton iterations, factorisations, failed solves."""
+        out = (ctypes.c_int64 * 4)()
+        self._ck(self.L.smc_meth_sweep_counters(self.ctx, out), "smc_meth_sweep_counters")
+        return {"bdf_steps": out[0], "newton_iters": out[1], "factorisations": out[2], "failed_solves": out[3]}
+
     def set_prior_mode(self, mode):
         """"mask" (default; the live branch of both reference drivers), "ratio_mask" (normal_pred and taylor,
         SMC_methanation_main.py:320-349) or "ratio" (normal_pred, :358-374)."""
