@@ -573,6 +573,29 @@ def test_full_run_device_rng_statistics(pkg, data, golden_run):
     assert 560 < out["logZ"] < 575
 
 
+def test_log_evidence_device_rng_vs_oracle_replicates(pkg, O, data):
+    """in device-RNG mode the streams differ from NumPy's, so the log-evidence is compared through
+    replicates - 8 seeds each of the oracle driver (NumPy stream) and of the GPU run (Philox) at N = 1000: the means
+    must agree within 4 combined standard errors, and the posterior means likewise."""
+    n, reps = 1000, 8
+    zo, zg, mo, mg = [], [], [], []
+    for k in range(reps):
+        o = O.run_smc(data, O.SMCSettings(), seed=100 + k, n_threads=0, record_mh=False)
+        zo.append(o["logZ"])
+        mo.append(o["p_pred"].mean(axis=0))
+    with make_engine(pkg, data, n) as eng:
+        for k in range(reps):
+            g = pkg.run_smc(eng, pkg.SMCSettings(), rng="device", verbose=False, seed_device=500 + k)
+            assert g["gamma"] == 1.0
+            zg.append(g["logZ"])
+            mg.append(g["p_pred"].mean(axis=0))
+    zo, zg, mo, mg = np.array(zo), np.array(zg), np.array(mo), np.array(mg)
+    se = np.sqrt(zo.var(ddof=1) / reps + zg.var(ddof=1) / reps)
+    assert abs(zo.mean() - zg.mean()) < 4 * se, (zo, zg)
+    sem = np.sqrt(mo.var(axis=0, ddof=1) / reps + mg.var(axis=0, ddof=1) / reps)
+    assert np.all(np.abs(mo.mean(axis=0) - mg.mean(axis=0)) < 4 * sem), (mo.mean(axis=0), mg.mean(axis=0))
+
+
 def test_philox_known_answer_and_prior_draw(pkg, data):
     """Philox4x32-10 known-answer vector (Random123) through a pure-Python restatement, and the device
     prior draw against it."""
