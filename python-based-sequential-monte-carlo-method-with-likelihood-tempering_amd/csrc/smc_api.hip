@@ -465,6 +465,7 @@ int smc_loglik(smc_ctx *c, int set, int64_t *n_failed, int64_t *rk_attempts) {
             launch_mm_loglik(c, c->set[set].theta, c->set[set].stride, c->n_local, c->set[set].lk, nullptr);
     }
     HIPC(c, hipGetLastError());
+    if (c->launch_failed) { c->launch_failed = false; return 1; }
     if (counters_end(c)) return 1;
     if (n_failed) *n_failed = (int64_t)c->h_counters->n_failed;
     if (rk_attempts) *rk_attempts = (int64_t)c->h_counters->rk_attempts;
@@ -833,6 +834,7 @@ int smc_moment_centered_local(smc_ctx *c, const double *mean, double *centered) 
 // ---- MH ------------------------------------------------------------------------------------------------
 static int mh_finish(smc_ctx *c, int64_t *accepted_now, int64_t *accepted_ever, int64_t *n_failed, int64_t *rk_attempts) {
     HIPC(c, hipGetLastError());
+    if (c->launch_failed) { c->launch_failed = false; return 1; }
     if (counters_end(c)) return 1;
     if (accepted_now) *accepted_now = (int64_t)c->h_counters->accepted_now;
     if (accepted_ever) *accepted_ever = (int64_t)c->h_counters->accepted_ever;

@@ -88,6 +88,7 @@ struct smc_ctx {
     // model
     int model_kind = 0;   // 0 none, 1 Michaelis-Menten, 2 methanation, 3 user model (hiprtc)
     void *user = nullptr; // UserModel (user_model.hip)
+    bool launch_failed = false;   // a launcher without a status (module launch) failed: the message is in err
     smc::MethModel meth{};
     double *d_mcond = nullptr, *d_mguess = nullptr, *d_mobs = nullptr, *d_mflows = nullptr, *d_mlk2 = nullptr;
     int *d_mstatus = nullptr;

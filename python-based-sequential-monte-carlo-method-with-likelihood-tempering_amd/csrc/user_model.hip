@@ -362,7 +362,12 @@ static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, 
     {
         ScopedTimer tm(c, SMC_T_SOLVE);
         (void)hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream);
-        (void)hipModuleLaunchKernel(u->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr);
+        const hipError_t e = hipModuleLaunchKernel(u->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr);
+        if (e != hipSuccess) {
+            smc_fail(c, (std::string("launch of the user-model kernel failed: ") + hipGetErrorString(e)).c_str());
+            c->launch_failed = true;
+            return;
+        }
     }
     const int64_t g = (n + 255) / 256;
     hipLaunchKernelGGL(user_finish_kernel, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, c->stream, theta, stride, n,
