@@ -671,13 +671,13 @@ def test_rccl_call_sequence_single_rank(pkg, data, golden_run, monkeypatch):
 # ---------------------------------------------------------------------------------------------------
 # multi-rank path with the real kernels on one GPU (loopback exchange instead of RCCL send/recv)
 # ---------------------------------------------------------------------------------------------------
-def _run_ranks(pkg, data, n, world, rng, seed):
+def _run_ranks(pkg, data, n, world, rng, seed, **settings):
     import threading
     from _thread_comm import ThreadWorld
     tw = ThreadWorld(world)
     nl = n // world
     engines = [pkg.HipEngine(nl, 3, device=0, n_global=n) for _ in range(world)]
-    s = pkg.SMCSettings(n_particle=n, seed=seed)
+    s = pkg.SMCSettings(n_particle=n, seed=seed, **settings)
     for r, e in enumerate(engines):
         e.set_model_mm(data.t, data.P_obs, data.S0)
         e.set_prior(s.priors)
@@ -730,6 +730,25 @@ def test_multi_rank_loopback_equals_single_rank(pkg, data, world):
     lk = np.concatenate([o["lk"] for o in outs])
     assert np.abs(p - ref["p_pred"]).max() < 1e-9
     assert relerr(lk, ref["lk"]).max() < TOL_LOGL
+
+
+@pytest.mark.parametrize("scheme", ["systematic", "multinomial"])
+def test_multi_rank_loopback_optional_schemes(pkg, data, scheme):
+    """The resampling options and the ESS bisection sharded over 3 ranks: thresholds, cumulative weights and the
+    bisection brackets are global quantities, so the sharded run must follow the single-rank one (a threshold within
+    rounding of a rank boundary may move one offspring; the schedule and evidence must still agree closely)."""
+    n, seed = 6144, 31
+    ref = _run_ranks(pkg, data, n, 1, "device", seed, resampling=scheme, ess_search="bisection")[0]
+    outs = _run_ranks(pkg, data, n, 3, "device", seed, resampling=scheme, ess_search="bisection")
+    assert ref["gamma"] == 1.0
+    for o in outs:
+        assert o["gamma"] == 1.0 and o["step"] == ref["step"]
+        assert np.allclose([r["gamma_new"] for r in o["records"]], [r["gamma_new"] for r in ref["records"]], rtol=1e-6, atol=0)
+        assert all(r["n_offspring"] in (n - 1, n) for r in o["records"])
+        assert abs(o["logZ"] - ref["logZ"]) < 1e-6 * abs(ref["logZ"])
+    p = np.concatenate([o["p_pred"] for o in outs])
+    same = np.all(p == ref["p_pred"], axis=1).mean()
+    assert same > 0.99 or np.abs(p.mean(axis=0) - ref["p_pred"].mean(axis=0)).max() < 3 * ref["p_pred"].std(axis=0).max() / np.sqrt(n)
 
 
 def test_multi_rank_resample_exchange_exact(pkg, O, data):
