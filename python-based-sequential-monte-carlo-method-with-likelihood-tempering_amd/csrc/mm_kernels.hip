@@ -24,6 +24,8 @@
 // whole sweep is ~200 B per particle against ~2e4 flop (DESIGN.md "Kernels").
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "mm_rk45.h"
 #include "philox.h"
 #include "prior.h"
@@ -363,6 +365,10 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
 }
 
 int query_solve_blocks_per_cu() {
+    if (const char *e = getenv("SMC_SOLVE_BLOCKS_PER_CU")) {   // experiments: persistent blocks (4 waves each) per CU
+        const int v = atoi(e);
+        if (v >= 1) return v;
+    }
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false>, kSolveBlock, 4096) != hipSuccess || nb < 1)
         nb = 2;
