@@ -1,13 +1,13 @@
 """Prototype (not product, not oracle): implicit-Euler + Richardson DAE integrator for the methanation model,
 to study step counts / stiffness before writing the C and HIP versions."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from scipy.linalg import solve_banded
 from oracle import methanation as M
 
 NX, NS = 51, 357
-GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
 cond = M.load_conditions(os.path.join(GOLD, "methanation_information.csv"))
 guess = M.initial_guess(cond)
 
