@@ -114,6 +114,31 @@ def test_dae_batch_vs_oracle(pkg, M, cond_guess):
     assert 150 * len(p0) < info["steps"] < 1000 * len(p0)
 
 
+def test_dae_kernel_converges_under_tolerance_refinement(pkg, M, cond_guess):
+    """K8 is parity-unpinned (no IDA): what can be shown without it is that the kernel's answer is the DAE's - the
+    outlet state at rtol = atol = 1e-6 lies within a few tolerance units of the one at 1e-8 and the one at 1e-7 several
+    times closer (the global error scales with the tolerance); 60 solves,
+    base parameters and one parameter vector from inside the prior box."""
+    cond, guess = cond_guess
+    lo, hi, pos = M.prior_box()
+    pr = M.BASEPARAMS.copy()
+    pr[:4] = (lo[pos] + (hi[pos] - lo[pos]) * np.random.RandomState(3).uniform(0.2, 0.8, 5))[:4]
+    p0 = np.concatenate([pkg.methanation.p0_rows(cond, M.BASEPARAMS), pkg.methanation.p0_rows(cond, pr)])
+    y0 = np.concatenate([guess[:30], guess[:30]])
+    outlet = [50, 101, 152, 203, 254, 305, 356]
+    sol, ok = {}, np.ones(len(p0), dtype=bool)
+    for tol in (1e-6, 1e-7, 1e-8):
+        _, status, states, _ = pkg.methanation.dae_solve_batch(p0, y0, rtol=tol, atol=tol, want_states=True)
+        ok &= status == 0              # the attempt budget (3000) is fixed: the most dynamic solves exceed it at 1e-8
+        sol[tol] = states[:, outlet]
+    assert ok[:30].all() and ok.sum() >= 40
+    scale = 1.0 + np.abs(sol[1e-8][ok])
+    e6 = np.abs(sol[1e-6][ok] - sol[1e-8][ok]) / scale
+    e7 = np.abs(sol[1e-7][ok] - sol[1e-8][ok]) / scale
+    assert e6.max() < 2e-5 and e7.max() < 3e-6, (e6.max(), e7.max())
+    assert e7.max() < 0.35 * e6.max()
+
+
 def test_dae_physics_and_failure_sentinel(pkg, M, cond_guess):
     cond, guess = cond_guess
     p0 = np.array([M.p0_tuple(cond, i, M.BASEPARAMS) for i in range(30)])
