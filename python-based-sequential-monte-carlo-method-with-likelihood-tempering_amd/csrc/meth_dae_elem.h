@@ -20,7 +20,7 @@
 //     Newton method only steers convergence: the converged step does not depend on it;
 //   * node-layout results reach the element layout through a 2.8 KB LDS staging row (Jacobian rows, right-hand
 //     sides) and come back the same way.
-// LDS per wave: differences array 8 x 7 x 51, L/U coefficients 51 x 24, staging 2 x 357 doubles = 38.4 KB, so four
+// LDS per wave: differences array 8 x 7 x 51, L/U coefficients 51 x 24, staging 357 + 408 doubles = 38.8 KB, so four
 // waves (one per SIMD) still share a CU.  Time stepping, Newton control and error tests are those of meth_dae.h.
 // PARITY UNPINNED against the reference's IDA (see meth_dae.h); checked against v2, the CPU build and the CPU checker.
 #pragma once
@@ -35,8 +35,8 @@ namespace meth {
 constexpr int kLdsD = 0;                         // D[k][f][node], k < 8
 constexpr int kLdsCf = kLdsD + 8 * 7 * kNX;      // per node 24: Ld[0..6],0 | Lx[0..6],0 | Ud[0..5],0,U65
 constexpr int kLdsB = kLdsCf + kNX * 24;         // b[node][7]  (also the staging row of the Jacobian transposition)
-constexpr int kLdsZ = kLdsB + kNX * 7;           // z / x [node][7]
-constexpr int kLdsDoubles = kLdsZ + kNX * 7;     // 4794 doubles = 38352 bytes
+constexpr int kLdsZ = kLdsB + kNX * 7;           // z / x [node][8]; slot 7 of a node takes the writes of the lanes that hold no result
+constexpr int kLdsDoubles = kLdsZ + kNX * 8;     // 4845 doubles = 38760 bytes
 
 struct DViewE {   // differences array, node-major within a row (only lanes < kNX may touch it)
     double *s;
@@ -234,7 +234,7 @@ struct ElemForward {
             t = fma(-lxI, zx, fma(-ldI, zprev, t));
         }
         const double zi = allsum_over_mc<Q>(X[I] * t);
-        if (mc == 0 && mr < 7) z[I * 7 + mr] = zi;
+        z[I * 8 + ((mc == 0 && mr < 7) ? mr : 7)] = zi;   // one unconditional store: no exec-mask round trip per step
         if constexpr (I + 1 < kNX) return ElemForward<IN>::run(L, cf, b, z, X, zi, bN, ldN, lxN);
         else return zi;
     }
@@ -246,9 +246,9 @@ struct ElemBackward {
     static __device__ __forceinline__ void run(const ElemLane &L, double *z, const double (&G)[kNX], double xnext, double zI) {
         constexpr int Q = I & 1, QN = 1 - Q, IN = (I > 0) ? I - 1 : 0;
         const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
-        const double zN = z[IN * 7 + min6(L.template mr<QN>())];
+        const double zN = z[IN * 8 + min6(L.template mr<QN>())];
         const double xi = zI - allsum_over_mc<Q>(G[I] * xnext);
-        if (mc == 0 && mr < 7) z[I * 7 + mr] = xi;
+        z[I * 8 + ((mc == 0 && mr < 7) ? mr : 7)] = xi;
         if constexpr (I > 0) ElemBackward<IN>::run(L, z, G, xi, zN);
     }
 };
@@ -284,14 +284,14 @@ __device__ __forceinline__ double elem_newton_iteration(int lane, double *lds, d
     SMC_PROF_ADD(st, 1);
     const double zlast = ElemForward<0>::run(L, cf, b, z, X, 0.0, b[min6(L.c)], 0.0, 0.0);
     SMC_PROF_ADD(st, 2);
-    ElemBackward<kNX - 2>::run(L, z, G, zlast, z[(kNX - 2) * 7 + min6(L.template mr<(kNX - 2) & 1>())]);
+    ElemBackward<kNX - 2>::run(L, z, G, zlast, z[(kNX - 2) * 8 + min6(L.template mr<(kNX - 2) & 1>())]);
     wave_lds_sync();
     SMC_PROF_ADD(st, 3);
     double sumsq = 0.0;
     if (node)
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) {
-            const double dx = z[lane * 7 + f];
+            const double dx = z[lane * 8 + f];
             const double sc = atol + rtol * fabs(yp[f]);
             const double q = dx / sc;
             sumsq += q * q;
