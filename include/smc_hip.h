@@ -237,13 +237,13 @@ int smc_timing_enable(smc_ctx *ctx, int enable);
 int smc_timing_reset(smc_ctx *ctx);
 int smc_timing_get(smc_ctx *ctx, int which, int64_t *launches, double *total_ms);
 
-/* ---- methanation model (configs 4-5): the rows that can be pinned today -------------------------------
+/* ---- methanation model (configs 4-5): context-free building blocks ---------------------------------------
  * State layout as in the reference: 357 = 7 fields x 51 axial nodes, field-major X[f*51+i],
  * f in {Ca,Cb,Cc,Cd,Ce,T,u} (SMC_methanation/methanation_set_likelihood.py:85-91); params = the
  * 18-tuple p0 of my_model (:164): 10 inlet/geometry scalars then the 8 kinetic parameters.
- * Context-free calls on host buffers (they allocate and free device memory per call): building blocks
- * that are parity-tested through the ABI; the implicit DAE integrator replacing my_model/IDA (:144-277)
- * is not built yet. */
+ * Context-free calls on host buffers (they allocate and free device memory per call), parity-tested through the
+ * ABI: residual, rate law and likelihood are pinned by the reference's own functions; smc_meth_dae_host (below)
+ * is the DAE integration replacing my_model/IDA (:144-277), parity-unpinned (no IDA in the image). */
 const char *smc_meth_last_error(void);
 /* res[n][357] = reaction(t, X, dX, params) (methanation_set_likelihood.py:69-139). */
 int smc_meth_residual_host(int device, const double *X, const double *dX, const double *params, int64_t n,
