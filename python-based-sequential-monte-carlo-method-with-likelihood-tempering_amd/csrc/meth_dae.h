@@ -39,6 +39,7 @@ namespace smc {
 namespace meth {
 
 constexpr int kNX = 51, kNS = 357, kNB = 49;
+constexpr int kDaeMaxAttempts = 3000;   // step attempts per solve before it is given up (status 1, sentinel flows)
 constexpr int kMaxOrder = 5, kNewtonMaxIter = 4;
 
 // workspace layout (doubles, per solve)

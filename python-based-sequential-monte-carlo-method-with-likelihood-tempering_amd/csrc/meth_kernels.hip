@@ -283,6 +283,7 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipGetDeviceProperties(&prop, device));
     const bool v1 = getenv("SMC_METH_DAE_V1") != nullptr;   // debug: the thread-per-solve version (meth_dae.h)
     const bool v2 = getenv("SMC_METH_DAE_V2") != nullptr;   // debug: lane = node scans (meth_dae_wave.h)
+    const int budget = getenv("SMC_METH_MAX_ATTEMPTS") ? atoi(getenv("SMC_METH_MAX_ATTEMPTS")) : kDaeMaxAttempts;
     int64_t nslots = ((n_solves + 63) / 64) * 64;
     const int64_t max_slots = (int64_t)prop.multiProcessorCount * 256;   // 4 waves per CU
     if (nslots > max_slots) nslots = max_slots;
@@ -305,17 +306,17 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipEventRecord(e0, 0));
     if (v1) {
         hipLaunchKernelGGL(dae_kernel, dim3((unsigned)(nslots / 64)), dim3(64), 0, 0, dws, nslots, dp, dy0, n_solves, tf,
-                           rtol, atol, h0, 3000, S, P_stp, dfl, dyf, dst, dcnt);
+                           rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
     } else if (!v2) {
         int64_t nwaves = (int64_t)prop.multiProcessorCount * 4;
         if (nwaves > n_solves) nwaves = n_solves;
         hipLaunchKernelGGL(dae_elem_kernel, dim3((unsigned)nwaves), dim3(64), kLdsDoubles * sizeof(double), 0, dp, dy0,
-                           n_solves, tf, rtol, atol, h0, 3000, S, P_stp, dfl, dyf, dst, dcnt);
+                           n_solves, tf, rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
     } else {
         int64_t nwaves = (int64_t)prop.multiProcessorCount * 4;
         if (nwaves > n_solves) nwaves = n_solves;
         hipLaunchKernelGGL(dae_wave_kernel, dim3((unsigned)nwaves), dim3(64), 8 * 7 * 64 * sizeof(double), 0, dp, dy0,
-                           n_solves, tf, rtol, atol, h0, 3000, S, P_stp, dfl, dyf, dst, dcnt);
+                           n_solves, tf, rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
     }
     MH(hipGetLastError());
     MH(hipEventRecord(e1, 0));

@@ -59,7 +59,7 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
                 for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
             }
         DaeStats st;
-        dae_elem_integrate(lds, lane, p, m.tf, m.rtol, m.atol, m.h0, 3000, st);
+        dae_elem_integrate(lds, lane, p, m.tf, m.rtol, m.atol, m.h0, kDaeMaxAttempts, st);
         if (lane == kNX - 1) {
             const double u = D(0, 6), T = D(0, 5);
             const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
