@@ -1,0 +1,42 @@
+"""Ragged / degenerate data shapes of the Michaelis-Menten path against the CPU checker: 1..7 experiments, 1..50 data times
+(a single time means t_span of zero length: solve_ivp returns without a step), output grids that do not start at 0,
+S0 = 0, fixed sigma; a repeated output time must be refused as solve_ivp refuses it (ivp.py:606-609)."""
+import numpy as np
+import pytest
+
+TOL = 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_random_data_shapes_vs_checker(pkg, O, seed):
+    rs = np.random.RandomState(100 + seed)
+    n_ex = int(rs.randint(1, 8))
+    n_t = int(rs.choice([1, 2, 3, 7, 40, 50]))
+    t = np.sort(rs.uniform(0, 12, (n_ex, n_t)), axis=1)
+    if seed % 2 == 0:
+        t[:, 0] = 0.0
+    S0 = rs.uniform(0.05, 3.0, n_ex)
+    if seed == 3:
+        S0[0] = 0.0
+    P_obs = rs.uniform(0, 2, (n_ex, n_t))
+    est_sigma = seed % 3 != 0
+    data = O.MMData(t=t, P_obs=P_obs, S0=S0)
+    n = 3000
+    th = np.column_stack([rs.uniform(0.05, 10, n), rs.uniform(0.05, 10, n), rs.uniform(0.01, 5, n)])
+    ref = O.mm_loglik_batch(th, data, est_sigma=est_sigma, sigma_fixed=0.7)[0]
+    with pkg.HipEngine(n, 3, device=0) as eng:
+        eng.set_model_mm(t, P_obs, S0, est_sigma=est_sigma, sigma_fixed=0.7)
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+    assert info["n_failed"] == 0
+    assert np.max(np.abs(lk - ref) / np.maximum(1.0, np.abs(ref))) < TOL, (n_ex, n_t)
+
+
+@pytest.mark.gpu
+def test_repeated_output_time_is_refused(pkg):
+    t = np.array([[0.0, 1.0, 1.0, 2.0]])
+    with pkg.HipEngine(8, 3, device=0) as eng:
+        with pytest.raises(pkg.SmcError, match="strictly increasing"):
+            eng.set_model_mm(t, np.zeros_like(t), np.array([1.0]))
