@@ -187,6 +187,44 @@ def test_resample_vs_oracle(pkg, O, data, n, gm):
     assert np.array_equal(got[3], ref[3])
 
 
+@pytest.mark.parametrize("pattern", ["equal", "one_hot", "two_spikes", "last_only", "underflow_tail"])
+@pytest.mark.parametrize("n", [7, 1024, 3001])
+def test_resample_degenerate_weights(pkg, O, data, n, pattern):
+    """Weight patterns at the edges of the resampler: all equal (every residual is a rounding residue), all mass on
+    one particle (one ancestor fills the whole output), two far-apart spikes, all mass on the last particle (the
+    running sum stays 0 until the end), weights that underflow to exactly 0 - offspring and gathered rows must equal
+    the sequential loop of Micmem_SMC_main.py:147-184 exactly."""
+    rs = np.random.RandomState(n)
+    lk = np.zeros(n)
+    if pattern == "one_hot":
+        lk[:] = -1e6
+        lk[n // 3] = 0.0
+    elif pattern == "two_spikes":
+        lk[:] = -50.0
+        lk[1], lk[n - 2] = 0.0, -0.3
+    elif pattern == "last_only":
+        lk[:] = -1e6
+        lk[n - 1] = 0.0
+    elif pattern == "underflow_tail":
+        lk = -np.arange(n, dtype=float) * 30.0
+    p_pred = rs.standard_normal((n, 3))
+    u, gm = 0.999, 1.0
+    mx = lk.max()
+    w = np.exp((lk - mx) * gm)
+    sum_w = np.sum(w)
+    p_filt, lk1 = np.zeros((n, 3)), np.zeros(n)
+    p_is, n_written, _ = O.resample(w / sum_w, u, p_pred, lk, p_filt, lk1)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, p_pred)
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        es = {"max_lk": mx, "gm": gm, "sum_weight": float(sum_w)}
+        out = pkg.resample(eng, pkg.SingleComm(), es, u, pkg.SMCSettings(n_particle=n), first_step=True)
+        assert np.array_equal(eng.download_offspring(), p_is)
+        assert out["n_offspring"] == n_written
+        assert np.array_equal(eng.download_particles(pkg.SMC_SET_FILT)[:n_written], p_filt[:n_written])
+        assert np.array_equal(eng.download_lk(pkg.SMC_SET_FILT)[:n_written], lk1[:n_written])
+
+
 def test_resample_golden_first_step(pkg, O, data, golden_run):
     """The reference run's first tempering step: weights from its first sweep, wrand from its seed."""
     g = golden_run
