@@ -40,3 +40,26 @@ def test_repeated_output_time_is_refused(pkg):
     with pkg.HipEngine(8, 3, device=0) as eng:
         with pytest.raises(pkg.SmcError, match="strictly increasing"):
             eng.set_model_mm(t, np.zeros_like(t), np.array([1.0]))
+
+
+@pytest.mark.gpu
+def test_weights_with_minus_infinity_and_huge_spread(pkg):
+    """sigma <= 0 gives logL = -inf (Micmem_likelihood.py:53-54): such particles must get weight exactly 0 in the fused
+    ESS sums, as exp((lk - max) * gm) does in NumPy; a spread of 1e6 in logL must not overflow anything."""
+    n = 10_000
+    rs = np.random.RandomState(5)
+    lk = rs.standard_normal(n) * 1e3
+    lk[::7] = -np.inf
+    lk[3] = 1e6
+    t = np.linspace(0, 1, 4)[None, :]
+    with pkg.HipEngine(n, 3, device=0) as eng:
+        eng.set_model_mm(t, np.zeros_like(t), np.array([1.0]))
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        mx = eng.max_lk_local()
+        assert mx == 1e6
+        gms = [1.0, 1e-3, 1e-6, 1e-9]
+        sw, sw2 = eng.ess_partials(mx, gms)
+    for k, gm in enumerate(gms):
+        with np.errstate(under="ignore"):
+            w = np.exp((lk - mx) * gm)
+        assert np.isfinite(sw[k]) and abs(sw[k] / w.sum() - 1) < 1e-12 and abs(sw2[k] / (w * w).sum() - 1) < 1e-12
