@@ -95,3 +95,79 @@ def test_user_model_compile_error_surfaces_through_the_engine(pkg):
     with pkg.HipEngine(64, 3, device=0) as eng:
         with pytest.raises(pkg.SmcError, match="does not compile"):
             eng.set_model_user("this is not HIP", 1, np.zeros((1, 4)), np.zeros((1, 4)))
+
+
+CHAIN8 = r"""
+// eight first-order steps in a row, y0 -> y1 -> ... -> y7, rate constants theta[0] (even links) / theta[1] (odd links)
+__device__ void smc_user_y0(const double *theta, const double *cond, double *y) {
+    y[0] = cond[0];
+    for (int i = 1; i < 8; ++i) y[i] = 0.0;
+}
+__device__ void smc_user_rhs(double t, const double *y, const double *theta, const double *cond, double *dydt) {
+    for (int i = 0; i < 8; ++i) {
+        const double k_in = theta[(i + 1) & 1], k_out = theta[i & 1];
+        dydt[i] = ((i > 0) ? k_in * y[i - 1] : 0.0) - ((i < 7) ? k_out * y[i] : 0.0);
+    }
+}
+__device__ double smc_user_obs(double t, const double *y, const double *theta, const double *cond) { return y[7]; }
+"""
+
+DIVERGING = r"""
+// the right-hand side turns NaN after t = 1: the step size collapses and the solve must be reported as failed
+__device__ void smc_user_y0(const double *theta, const double *cond, double *y) { y[0] = 1.0; }
+__device__ void smc_user_rhs(double t, const double *y, const double *theta, const double *cond, double *dydt) {
+    dydt[0] = (t > 1.0) ? sqrt(-1.0 - y[0] * y[0]) : -theta[0] * y[0];
+}
+__device__ double smc_user_obs(double t, const double *y, const double *theta, const double *cond) { return y[0]; }
+"""
+
+
+@pytest.mark.gpu
+def test_eight_state_user_model_follows_scipy(pkg):
+    """SMC_USER_MAX_STATES = 8 states: the generic kernel against solve_ivp(RK45) on the host."""
+    from scipy.integrate import solve_ivp
+    rs = np.random.RandomState(1)
+    n_ex, n_t, n = 2, 25, 64
+    t = np.tile(np.linspace(0.0, 20.0, n_t), (n_ex, 1))
+    A0 = np.array([1.0, 3.0])
+    obs = rs.uniform(0, 1, (n_ex, n_t))
+    th = np.column_stack([rs.uniform(0.2, 2, n), rs.uniform(0.2, 2, n), rs.uniform(0.05, 0.5, n)])
+
+    def rhs(_t, y, ka, kb):
+        d = np.zeros(8)
+        for i in range(8):
+            k_in, k_out = (kb, ka) if i % 2 == 0 else (ka, kb)
+            d[i] = (k_in * y[i - 1] if i > 0 else 0.0) - (k_out * y[i] if i < 7 else 0.0)
+        return d
+    ref = np.empty(n)
+    for i, (ka, kb, sg) in enumerate(th):
+        r2 = 0.0
+        for e in range(n_ex):
+            y0 = np.zeros(8)
+            y0[0] = A0[e]
+            sol = solve_ivp(rhs, [t[e, 0], t[e, -1]], y0, method="RK45", t_eval=t[e], rtol=1e-3, atol=1e-6, args=(ka, kb))
+            r2 += np.sum((obs[e] - sol.y[7]) ** 2)
+        ref[i] = n_ex * (-0.5 * n_t) * np.log(2 * np.pi * sg * sg) - r2 / (2 * sg * sg)
+    priors = {"ka": {"dist": "uniform", "low": 0, "high": 3}, "kb": {"dist": "uniform", "low": 0, "high": 3},
+              "sigma": {"dist": "uniform", "low": 0, "high": 1}}
+    with pkg.HipEngine(n, 3, device=0) as eng:
+        eng.set_prior(priors)
+        eng.set_model_user(CHAIN8, 8, t, obs, cond=A0[:, None])
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+    assert info["n_failed"] == 0
+    assert np.max(np.abs(lk - ref) / np.maximum(1.0, np.abs(ref))) < 1e-6
+
+
+@pytest.mark.gpu
+def test_user_model_failure_is_counted_and_the_kernel_returns(pkg):
+    n = 256
+    t = np.linspace(0.0, 2.0, 10)[None, :]
+    th = np.column_stack([np.full(n, 0.5), np.full(n, 1.0), np.full(n, 0.1)])
+    with pkg.HipEngine(n, 3, device=0) as eng:
+        eng.set_prior(pkg.SMCSettings().priors)
+        eng.set_model_user(DIVERGING, 1, t, np.zeros_like(t))
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+    assert info["n_failed"] == n
