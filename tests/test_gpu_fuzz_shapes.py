@@ -63,3 +63,25 @@ def test_weights_with_minus_infinity_and_huge_spread(pkg):
         with np.errstate(under="ignore"):
             w = np.exp((lk - mx) * gm)
         assert np.isfinite(sw[k]) and abs(sw[k] / w.sum() - 1) < 1e-12 and abs(sw2[k] / (w * w).sum() - 1) < 1e-12
+
+
+@pytest.mark.gpu
+def test_ess_searches_on_degenerate_likelihoods(pkg):
+    """Both gamma searches at the two ends: equal likelihoods (ESS = 1 for every gamma: the whole remaining increment is
+    taken, gamma = 1.0 exactly) and one particle towering above the rest (ESS ~ 1/N for every increment worth
+    taking: the back-off runs through its 80 candidates and warns, main:141-144; the bisection ends on its smallest
+    bracket and warns likewise)."""
+    n = 4096
+    t = np.linspace(0, 1, 4)[None, :]
+    for how in ("backoff", "bisection"):
+        s = pkg.SMCSettings(n_particle=n, ess_search=how)
+        with pkg.HipEngine(n, 3, device=0) as eng:
+            eng.set_model_mm(t, np.zeros_like(t), np.array([1.0]))
+            eng.upload_lk(pkg.SMC_SET_PRED, np.full(n, -12.5))
+            es = pkg.ess_search(eng, pkg.SingleComm(), 0.25, s)
+            assert es["gamma_new"] == 1.0 and not es["warning"] and abs(es["ess"] - 1.0) < 1e-12
+            lk = np.full(n, -1e15)          # even the 80th back-off candidate (0.75 * 0.7**79 ~ 4e-13) leaves weight exp(-430)
+            lk[17] = 0.0
+            eng.upload_lk(pkg.SMC_SET_PRED, lk)
+            es = pkg.ess_search(eng, pkg.SingleComm(), 0.25, s)
+            assert es["warning"] and 0.25 < es["gamma_new"] < 0.25 + 1e-8 and es["ess"] < 0.5
