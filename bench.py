@@ -45,6 +45,27 @@ def load_mm_data():
     return z["t"], z["P_obs"], z["S0"]
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a container on a 256-core
+    host may be limited to a 16-CPU share; sizing the pool by the mask would oversubscribe it and misreport `cores`)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(sample_seconds_target=15.0):
     """The reference's per-particle path (SciPy solve_ivp RK45 per particle x experiment, one task per
     particle on a process pool = the Ray fan-out, Micmem_likelihood.py:83) timed on this box's host
@@ -53,10 +74,10 @@ def cpu_baseline(sample_seconds_target=15.0):
     reference's files do not travel to this box)."""
     O = entry.load_oracle()
     data = O.MMData.load()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = effective_cpus()
     rs = np.random.RandomState(0)
-    per_core_rate = 78.0  # likelihoods/s/core measured in the survey; only used to size the sample
-    m = int(max(cores * 8, min(20000, per_core_rate * cores * sample_seconds_target)))
+    per_core_rate = 230.0  # likelihoods/s/core on the GPU box's host CPU (78 in the survey container); sizes the sample only
+    m = int(max(cores * 8, min(60000, per_core_rate * cores * sample_seconds_target)))
     theta = np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((m, 3)) * np.array([0.025, 0.0295, 0.00094])
     t0 = time.perf_counter()
     lk = O.mm_loglik_batch_scipy(theta, data, n_workers=cores)
