@@ -10,6 +10,22 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cpus():
+    """Affinity mask capped by the cgroup CPU quota (the GPU box shows 256 cores but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# the checker's OpenMP loops default to one thread per visible core: do not oversubscribe a CPU quota
+os.environ.setdefault("OMP_NUM_THREADS", str(_usable_cpus()))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
