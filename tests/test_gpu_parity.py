@@ -513,6 +513,21 @@ def test_resume_from_dump_is_bit_identical(pkg, data, tmp_path):
     assert [r["n_accept"] for r in cont["records"]] == [r["n_accept"] for r in tail]
 
 
+def test_resume_in_numpy_parity_mode_continues_the_reference_run(pkg, data, golden_run, tmp_path):
+    """Parity mode draws from NumPy's global generator: the state file keeps that generator's state, so a run resumed
+    after step 5 ends exactly where the reference's uninterrupted run ends (its final particles, its next random)."""
+    g = golden_run
+    with make_engine(pkg, data, 1000) as eng:
+        pkg.run_smc(eng, pkg.SMCSettings(), rng="numpy", verbose=False, dump_dir=str(tmp_path))
+    np.random.seed(12345)                                   # whatever happened to the global stream in between
+    with make_engine(pkg, data, 1000) as eng:
+        cont = pkg.run_smc(eng, pkg.SMCSettings(), rng="numpy", verbose=False, resume_from=(str(tmp_path), 5))
+    assert cont["step"] == int(g["final_step"]) and cont["gamma"] == 1.0
+    assert np.abs(cont["p_pred"] - g["final_p_pred"]).max() < 1e-9
+    assert np.array_equal([r["gamma_new"] for r in cont["records"]], g["sched_gamma"][5:])
+    assert np.random.rand() == float(g["next_rand_after_run"])
+
+
 def test_systematic_resampling_option(pkg, data):
     """BASELINE.json names systematic resampling; the reference only has the residual variant, so the pin is the
     textbook definition in NumPy: offspring_i = #{k : (u + k)/N in (C_{i-1}, C_i]} with C = cumsum(w)."""
