@@ -99,6 +99,16 @@ int smc_user_model_check(const char *source, int n_states, int dim, char *log, i
 /* Methanation model: device-counted work of the LAST smc_loglik / smc_mh_step_* call (the counts the K8
  * roofline is built from): out = {accepted BDF steps, Newton iterations, Jacobian factorisations, failed solves}. */
 int smc_meth_sweep_counters(smc_ctx *ctx, int64_t out[4]);
+/* Completeness of the LAST methanation sweep: out = {DAE solves asked for (live (particle, experiment) pairs), solves
+ * finished, live items whose status was still the pre-sweep poison value when the likelihood was formed, waves that were
+ * incomplete at a dequeue}.  A sweep with out[1] != out[0] or out[2], out[3] != 0 makes smc_loglik / smc_mh_step_* fail
+ * (the reference's counterpart is the bare except of methanation_set_likelihood.py:234-254: there a lost solve would
+ * surface as an exception at ray.get). */
+int smc_meth_sweep_check(smc_ctx *ctx, int64_t out[4]);
+/* Outlet flows (n x n_data x 5, the F_k of methanation_set_likelihood.py:204-208; -10000 where the solve failed, :244-249)
+ * and solver status (n x n_data: 0 solved, 1 given up, -1 not solved in this sweep = masked proposal) of the LAST sweep -
+ * what my_model returns per particle before my_loglike reduces it (the reference keeps them as C_l_ for its plots). */
+int smc_meth_download_solves(smc_ctx *ctx, double *flows, int32_t *status, int64_t n);
 /* Independent priors, one per parameter: kind[i] in {SMC_PRIOR_UNIFORM, SMC_PRIOR_NORMAL, SMC_PRIOR_FLAT}; (a,b) =
  * (low,high) or (mu,sigma).  Used by the support mask of cal_prior (Micmem_SMC_main.py:60-90,
  * 224-228) and by smc_sample_prior_device. */

@@ -81,7 +81,7 @@ __device__ __forceinline__ double allsum_across8(double v) {
     return v;
 }
 // all 64 lanes (DPP + permlane swaps instead of six ds_bpermute rounds)
-__device__ __forceinline__ double allsum_wave(double v) { return allsum_across8(allsum_group8(v)); }
+__device__ __forceinline__ double allsum_wave(double v) { return wave_uniform(allsum_across8(allsum_group8(v))); }   // scalar: see wave_uniform
 template <int Q>
 __device__ __forceinline__ double allsum_over_mc(double v) {   // Q = node parity: the column index is c (0) or r (1)
     if (Q == 0) return allsum_group8(v);
@@ -366,7 +366,18 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
     bool lu_valid = false, force_rebuild = false;
     double c_lu = 0.0;
     double yp[7], y[7], psi[7], dd[7];
-    while (t < tf) {  // one iteration = one step attempt (all quantities below are wave-uniform)
+    for (;;) {  // one iteration = one step attempt
+        // The state that steers the attempt, pinned to scalars (meth_dae_wave.h: wave_uniform): the values are equal in all
+        // lanes anyway; this tells the compiler, so that every branch below is a scalar branch taken by the whole wave.
+        t = wave_uniform(t);
+        h_abs = wave_uniform(h_abs);
+        c_lu = wave_uniform(c_lu);
+        order = __builtin_amdgcn_readfirstlane(order);
+        n_equal = __builtin_amdgcn_readfirstlane(n_equal);
+        attempts = __builtin_amdgcn_readfirstlane(attempts);
+        lu_valid = __builtin_amdgcn_readfirstlane((int)lu_valid) != 0;
+        force_rebuild = __builtin_amdgcn_readfirstlane((int)force_rebuild) != 0;
+        if (!(t < tf)) break;
         if (h_abs < 1e-14 * fmax(1.0, t) || attempts >= max_attempts) { st.status = 1; break; }
         ++attempts;
         double t_new = t + h_abs;
@@ -375,6 +386,8 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
             { SMC_PROF_BEGIN(); elem_change_D(D, order, fabs(t_new - t) / h_abs, node); SMC_PROF_ADD(st, 5); }
             n_equal = 0;
         }
+        t_new = wave_uniform(t_new);   // elem_change_D branches on the lane: what joins behind it is re-pinned
+        n_equal = __builtin_amdgcn_readfirstlane(n_equal);
         const double h = t_new - t;
         h_abs = fabs(h);
         const double c = h / bdf_alpha(order);
@@ -500,8 +513,9 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
         SMC_PROF_ADD(st, 10);  // D update + order-selection norms
         if (!select) continue;
         const double inf = __longlong_as_double(0x7ff0000000000000LL);
-        const double em = (order > 1) ? sqrt(allsum_wave(sm) / (6 * kNX)) : inf;
-        const double ep = (order < kMaxOrder) ? sqrt(allsum_wave(sp) / (6 * kNX)) : inf;
+        const double em_s = sqrt(allsum_wave(sm) / (6 * kNX)), ep_s = sqrt(allsum_wave(sp) / (6 * kNX));   // both sums: no
+        const double em = (order > 1) ? em_s : inf;                                                           // branch around
+        const double ep = (order < kMaxOrder) ? ep_s : inf;                                                   // a wave exchange
         const double fm = pow(em, -1.0 / order), f0 = pow(error_norm, -1.0 / (order + 1)), fp = pow(ep, -1.0 / (order + 2));
         double best = fm;
         int delta = -1;
@@ -513,6 +527,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
         { SMC_PROF_BEGIN(); elem_change_D(D, order, factor, node); SMC_PROF_ADD(st, 5); }
         n_equal = 0;
     }
+    st.status = __builtin_amdgcn_readfirstlane(st.status);
 #ifdef SMC_METH_PROFILE
     st.prof[4] = clock64() - prof_start_;
 #endif

@@ -24,10 +24,36 @@
 namespace smc {
 namespace meth {
 
+// Wave-uniform loop control, BY CONSTRUCTION.  Everything that steers a loop of the one-wave-per-solve kernels (the index
+// of the next solve, error and Newton norms, hence t, h, the order ...) has the same value in all 64 lanes - but a value
+// that reaches the branch through a VGPR (a shuffle, a butterfly sum) is "divergent" to the compiler, which then manages
+// the loop with exec masks and may run the two sides of an `if (lane == 0)` as separate trips through the loop.  That is
+// what happened to the first dequeue loop of meth_particles_dae_kernel (`for (;;)` + lane-0 atomicAdd + __shfl + `continue`):
+// lanes 1..63 reached the ds_bpermute of the __shfl with lane 0 parked on the atomic's side, read 0 from the inactive lane
+// and solved item 0 for ever (ISA excerpts: profiles/r02_k8_dequeue_hang_isa.md).  v_readfirstlane puts such a value into
+// an SGPR: the branches on it become scalar, no lane can leave a loop or skip a statement on its own, and the DPP / permlane
+// / LDS exchanges of the integrator always run with the full wave.
+__device__ __forceinline__ double wave_uniform(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// Next index of a work counter shared by all waves, as a scalar: lane 0 performs the atomic, the join is full-wave.
+// `split` is set when the wave is NOT complete at the join (never, unless the compiler splits the wave again; the host
+// fails the sweep on it).
+__device__ __forceinline__ long long wave_dequeue(unsigned long long *counter, int lane, unsigned &split) {
+    unsigned long long nxt = 0;
+    if (lane == 0) nxt = atomicAdd(counter, 1ULL);
+    split |= (unsigned)(__builtin_amdgcn_read_exec() != ~0ull);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nxt);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nxt >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ double wave_allsum(double v) {
 SMC_UNROLL
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    return wave_uniform(v);
 }
 __device__ __forceinline__ double lane_bcast(double v, int src) {  // src is wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);

@@ -153,10 +153,9 @@ dae_elem_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
     extern __shared__ double lds[];  // kLdsDoubles
     const int lane = threadIdx.x;
     const DViewE D{lds + kLdsD, lane};
-    for (;;) {
-        unsigned long long nxt = 0;
-        if (lane == 0) nxt = atomicAdd(&counters[5], 1ULL);
-        const int64_t sidx = (int64_t)__shfl(nxt, 0);
+    unsigned split = 0;
+    for (int64_t it = 0; it <= n_solves; ++it) {   // scalar loop control (meth_dae_wave.h: wave_dequeue)
+        const int64_t sidx = wave_dequeue(&counters[5], lane, split);
         if (sidx >= n_solves) break;
         double p[18];
         for (int q = 0; q < 18; ++q) p[q] = p0_all[sidx * 18 + q];
@@ -188,7 +187,9 @@ dae_elem_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
         }
         if (y_final && lane < kNX)
             for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + lane] = D(0, f);
+        if (lane == 0) atomicAdd(&counters[6], 1ULL);   // finished solves
     }
+    if (split && lane == 0) atomicAdd(&counters[7], 1ULL);
 }
 
 }  // namespace meth
@@ -329,10 +330,17 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipMemcpy(flows, dfl, (size_t)n_solves * 5 * 8, hipMemcpyDeviceToHost));
     MH(hipMemcpy(status, dst, (size_t)n_solves * sizeof(int), hipMemcpyDeviceToHost));
     if (y_final) MH(hipMemcpy(y_final, dyf, (size_t)n_solves * kNS * 8, hipMemcpyDeviceToHost));
-    if (stats) {
-        unsigned long long h[4];
+    {
+        unsigned long long h[8];
         MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
-        for (int q = 0; q < 4; ++q) stats[q] = (int64_t)h[q];
+        if (stats)
+            for (int q = 0; q < 4; ++q) stats[q] = (int64_t)h[q];
+        if (!v1 && !v2 && (h[6] != (unsigned long long)n_solves || h[7] != 0)) {   // every solve exactly once, whole waves only
+            g_meth_err = "dae_elem_kernel: " + std::to_string(h[6]) + " of " + std::to_string(n_solves) +
+                         " solves finished, " + std::to_string(h[7]) + " waves split at a dequeue";
+            for (void *q : bufs) (void)hipFree(q);
+            return 1;
+        }
     }
 #ifdef SMC_METH_PROFILE
     {

@@ -17,6 +17,8 @@ namespace smc {
 
 using namespace meth;
 
+constexpr int kStatusUnsolved = -1;   // what launch_solves fills the status array with before a sweep
+
 // work list of an MH sweep: the (particle, experiment) pairs of proposals inside the prior support; queue[1] counts them
 __global__ void meth_worklist_kernel(const uint8_t *__restrict__ p0mask, int64_t n, int n_data, int64_t *__restrict__ list,
                                      unsigned long long *__restrict__ queue) {
@@ -28,7 +30,10 @@ __global__ void meth_worklist_kernel(const uint8_t *__restrict__ p0mask, int64_t
 
 // K8 over (particle, experiment) pairs of the resident set; one wave per solve (meth_dae_elem.h), persistent waves
 // that take solves from an atomic counter (a failed solve costs ~9 ordinary ones).  list == nullptr: all n * n_data
-// pairs; otherwise the queue[1] pairs of the work list.  Every wave leaves after at most count + 1 dequeues.
+// pairs; otherwise the queue[1] pairs of the work list.  Loop control is scalar (wave_dequeue, wave_uniform in
+// meth_dae_wave.h): the position and the count live in SGPRs, so the whole wave breaks together.  The counter only
+// grows, so every wave leaves after its first position >= count; the hard bound of count + 1 trips is a second exit.
+// Bookkeeping for the host (smc_meth_sweep_check): expected = count, completed += 1 per finished solve, wave_split.
 __global__ void __launch_bounds__(64)
 meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
                           const int64_t *__restrict__ list, double *__restrict__ flows, int *__restrict__ status,
@@ -37,10 +42,10 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
     const int lane = threadIdx.x;
     const DViewE D{lds + kLdsD, lane};
     const int64_t count = list ? (int64_t)queue[1] : n * m.n_data;
+    if (blockIdx.x == 0 && lane == 0) counters->expected_solves = (unsigned long long)count;
+    unsigned split = 0;
     for (int64_t it = 0; it <= count; ++it) {
-        unsigned long long nxt = 0;
-        if (lane == 0) nxt = atomicAdd(&queue[0], 1ULL);
-        const int64_t pos = (int64_t)__shfl(nxt, 0);
+        const int64_t pos = wave_dequeue(&queue[0], lane, split);
         if (pos >= count) break;
         const int64_t w = list ? list[pos] : pos;
         const int64_t particle = w / m.n_data;
@@ -73,17 +78,26 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
             atomicAdd(&counters->rk_attempts, (unsigned long long)st.steps);
             atomicAdd(&counters->newton_iters, (unsigned long long)st.newton_iters);
             atomicAdd(&counters->factorisations, (unsigned long long)st.nlu);
+            atomicAdd(&counters->completed_solves, 1ULL);
             if (st.status != 0) atomicAdd(&counters->failed_solves, 1ULL);
         }
     }
+    if (split && lane == 0) atomicAdd(&counters->wave_split, 1ULL);
 }
 
 // my_loglike per particle from its 5 x n_data flows (:280-300); sigma = the particle's last estimated parameter
-// when est_sigma (methanation_functions.py:50-53)
+// when est_sigma (methanation_functions.py:50-53).  The status array is poisoned (kStatusUnsolved) before every sweep:
+// a live particle with an experiment nobody solved gets NaN and is counted, so stale flows can never pass as a result.
 __global__ void meth_particle_loglike_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
-                                             const double *__restrict__ flows, double *__restrict__ lk) {
+                                             const double *__restrict__ flows, const int *__restrict__ status,
+                                             const uint8_t *__restrict__ p0mask, SweepCounters *__restrict__ counters,
+                                             double *__restrict__ lk) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (p0mask && p0mask[p] == 0) {   // masked proposal: nothing was solved, the accept kernel keeps lk1
+        lk[p] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
     double sigma = m.sigma_fixed;
     if (m.est_sigma) {
         sigma = m.base[8];
@@ -99,6 +113,12 @@ __global__ void meth_particle_loglike_kernel(MethModel m, const double *__restri
             acc += d * d;
         }
         total += c * acc - l;
+    }
+    int unsolved = 0;
+    for (int e = 0; e < m.n_data; ++e) unsolved += (status[p * m.n_data + e] == kStatusUnsolved);
+    if (unsolved) {
+        atomicAdd(&counters->unsolved_items, (unsigned long long)unsolved);
+        total = __longlong_as_double(0x7ff8000000000000LL);
     }
     lk[p] = total;
 }
@@ -211,7 +231,14 @@ static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int
     if (nwaves > n * m.n_data) nwaves = n * m.n_data;
     if (nwaves < 1) nwaves = 1;
     ScopedTimer tm(ctx, SMC_T_SOLVE);
-    (void)hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    hipError_t e = hipMemsetAsync(ctx->d_queue, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess)   // 0xff bytes = kStatusUnsolved in every int
+        e = hipMemsetAsync(ctx->d_mstatus, 0xff, (size_t)n * m.n_data * sizeof(int), ctx->stream);
+    if (e != hipSuccess) {
+        ctx->err = std::string("methanation sweep: clearing the work queue / status array failed: ") + hipGetErrorString(e);
+        ctx->launch_failed = true;
+        return;
+    }
     const int64_t *list = nullptr;
     if (p0mask) {
         hipLaunchKernelGGL(meth_worklist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p0mask, n,
@@ -225,8 +252,9 @@ static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk) {
     if (n <= 0) return;
     launch_solves(ctx, theta, stride, n, nullptr);
+    if (ctx->launch_failed) return;
     hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
-                       theta, stride, n, ctx->d_mflows, lk);
+                       theta, stride, n, ctx->d_mflows, ctx->d_mstatus, nullptr, ctx->d_counters, lk);
 }
 
 void launch_generic_propose(smc_ctx *ctx, int64_t n, const MHParams &mh) {
@@ -251,8 +279,9 @@ void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
     ParticleSet &P = ctx->set[SMC_SET_PRED];
     launch_generic_propose(ctx, n, mh);
     launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0);
+    if (ctx->launch_failed) return;
     hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
-                       P.theta, P.stride, n, ctx->d_mflows, ctx->d_mlk2);
+                       P.theta, P.stride, n, ctx->d_mflows, ctx->d_mstatus, ctx->d_p0, ctx->d_counters, ctx->d_mlk2);
     launch_generic_accept(ctx, n, mh, ctx->d_mlk2);
 }
 

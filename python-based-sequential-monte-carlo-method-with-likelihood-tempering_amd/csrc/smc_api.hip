@@ -343,6 +343,27 @@ int smc_meth_sweep_counters(smc_ctx *c, int64_t out[4]) {
     return 0;
 }
 
+int smc_meth_sweep_check(smc_ctx *c, int64_t out[4]) {
+    if (!c) return fail(nullptr, "NULL context");
+    out[0] = (int64_t)c->h_counters->expected_solves;
+    out[1] = (int64_t)c->h_counters->completed_solves;
+    out[2] = (int64_t)c->h_counters->unsolved_items;
+    out[3] = (int64_t)c->h_counters->wave_split;
+    return 0;
+}
+
+int smc_meth_download_solves(smc_ctx *c, double *flows, int32_t *status, int64_t n) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (c->model_kind != 2) return fail(c, "smc_set_model_methanation has not been called");
+    if (n < 0 || n > c->n_local) return fail(c, "n exceeds the context capacity");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t items = (size_t)n * c->meth.n_data;
+    if (flows) HIPC(c, hipMemcpyAsync(flows, c->d_mflows, items * 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) HIPC(c, hipMemcpyAsync(status, c->d_mstatus, items * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int smc_set_resampling(smc_ctx *c, int scheme) {
     if (!c) return fail(nullptr, "NULL context");
     if (scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC && scheme != SMC_RESAMPLE_SYSTEMATIC && scheme != SMC_RESAMPLE_MULTINOMIAL)
@@ -447,6 +468,15 @@ static int counters_begin(smc_ctx *c) {
 static int counters_end(smc_ctx *c) {
     HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(SweepCounters), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->model_kind == 2) {   // every (particle, experiment) item the sweep asked for must have been solved exactly once
+        const SweepCounters &k = *c->h_counters;
+        if (k.completed_solves != k.expected_solves || k.unsolved_items != 0 || k.wave_split != 0) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "methanation sweep incomplete: %llu of %llu DAE solves finished, %llu live items unsolved, "
+                     "%llu waves split at a dequeue", k.completed_solves, k.expected_solves, k.unsolved_items, k.wave_split);
+            return fail(c, buf);
+        }
+    }
     return 0;
 }
 

@@ -65,6 +65,10 @@ struct MHParams {    // passed by value to the fused MH kernel
 struct SweepCounters {  // device-side integer counters (order-independent atomics)
     unsigned long long n_failed, rk_attempts, accepted_now, accepted_ever;
     unsigned long long newton_iters, factorisations, failed_solves;   // K8 only (methanation)
+    // K8 sweep bookkeeping: solves the DAE kernel was asked for / finished, live items the likelihood kernel found
+    // unsolved (status still poisoned), waves that were incomplete at a dequeue.  A sweep is valid only if
+    // completed == expected and the other two are zero (checked on the host after every sweep).
+    unsigned long long expected_solves, completed_solves, unsolved_items, wave_split;
 };
 
 struct EventPair {

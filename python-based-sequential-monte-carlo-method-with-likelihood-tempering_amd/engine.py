@@ -151,6 +151,22 @@ class HipEngine:
         self._ck(self.L.smc_meth_sweep_counters(self.ctx, out), "smc_meth_sweep_counters")
         return {"bdf_steps": out[0], "newton_iters": out[1], "factorisations": out[2], "failed_solves": out[3]}
 
+    def meth_sweep_check(self):
+        """Completeness of the last methanation sweep (the library already fails the sweep when these disagree)."""
+        out = (ctypes.c_int64 * 4)()
+        self._ck(self.L.smc_meth_sweep_check(self.ctx, out), "smc_meth_sweep_check")
+        return {"expected_solves": out[0], "completed_solves": out[1], "unsolved_items": out[2], "wave_split": out[3]}
+
+    def meth_download_solves(self, n=None):
+        """Outlet flows (n, n_data, 5) and solver status (n, n_data) of the last methanation sweep."""
+        n = self.n_local if n is None else n
+        nd = self.model[1]
+        flows = np.empty((n, nd, 5))
+        status = np.empty((n, nd), dtype=np.int32)
+        self._ck(self.L.smc_meth_download_solves(self.ctx, _dp(flows), status.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n),
+                 "smc_meth_download_solves")
+        return flows, status
+
     def set_prior_mode(self, mode):
         """"mask" (default; the live branch of both reference drivers), "ratio_mask" (normal_pred and taylor,
         SMC_methanation_main.py:320-349) or "ratio" (normal_pred, :358-374)."""
