@@ -11,16 +11,23 @@ particle population: every stage of the hot path (likelihood sweep, fused ESS se
 moments, fused Metropolis sweeps) runs inside the timed region, with device RNG so that nothing but
 a few scalars per stage crosses PCIe.  value = particle-mutation-steps executed / wall time.
 
-Launch:  python bench.py --gpus 1 --steps 3 --warmup 1
+Launch:  python bench.py --gpus N --steps K --warmup W          (N > 1: this process spawns the N rank processes itself,
+                                                                  before anything touches a GPU, and relays rank 0's line)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-                --master-port P bench.py --gpus N --steps K --warmup W
+                --master-port P bench.py --gpus N --steps K --warmup W      (RANK / LOCAL_RANK / WORLD_SIZE from the env)
+No torch anywhere: the ranks talk through the engine's RCCL communicator; its 128-byte id travels through a file.
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -105,19 +112,144 @@ def cpu_baseline(sample_seconds_target=15.0):
             "ess_iters_per_s_n1e6_1core": 1.0 / dt_e}
 
 
-def make_comm(pkg, eng, rank, world):
-    """SingleComm, or the engine's RCCL communicator (torch.distributed/gloo only carries RCCL's 128-byte id)."""
-    if world == 1:
-        return pkg.SingleComm()
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+def kernel_source_sha():
+    """sha256 over the sources libsmc_hip.so is built from: ties a profile (profiles/*pmc*summary.json) to a kernel revision."""
+    h = hashlib.sha256()
+    csrc = os.path.join(entry.PKG_DIR, "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
+                    [os.path.join(ROOT, "include", "smc_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel, n_local):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (tools/pmc_summary.py), but only
+    if that profile was taken on THIS kernel revision at THIS population size; otherwise (None, why)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.json")))
+    if not files:
+        return None, "no PMC summary under profiles/"
+    f = files[-1]
+    try:
+        pmc = json.load(open(f))
+        meta = pmc.get("meta", {})
+        if meta.get("kernel_source_sha") != kernel_source_sha():
+            return None, f"{os.path.basename(f)} was taken on another kernel revision ({meta.get('kernel_source_sha')})"
+        if int(meta.get("particles_per_gpu", -1)) != int(n_local):
+            return None, f"{os.path.basename(f)} was taken at {meta.get('particles_per_gpu')} particles per GPU"
+        # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes fetched (MI355X_MICROARCH.md,
+        # HBM section; confirmed on mm_propose_kernel in round 1: 11.8 MiB reported for 24 MB read)
+        b = (2 * pmc["pmc_fetch"][kernel]["avg_counter_value"] + pmc["pmc_write"][kernel]["avg_counter_value"]) * 1024
+        return b, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{meta.get('command')}` ({os.path.basename(f)}), FETCH_SIZE doubled"
+    except (KeyError, ValueError, OSError) as e:
+        return None, f"{os.path.basename(f)}: {e!r}"
+
+
+# ---- ranks ------------------------------------------------------------------------------------------------------------
+def rendezvous_dir():
+    """Where rank 0 leaves RCCL's unique id for the other ranks of this node.  Self-launched: a fresh directory made by the
+    parent (SMC_BENCH_RDZV).  Under torch.distributed.run: derived from what all ranks of one launch share."""
+    d = os.environ.get("SMC_BENCH_RDZV")
+    if not d:
+        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+        d = os.path.join(tempfile.gettempdir(), f"smc_bench_rdzv_{tag}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def bootstrap_via_file(rank):
+    """bootstrap(uid_or_None) -> uid for comm.RcclComm: rank 0 writes the 128 bytes (atomically), the others wait for them."""
+    path = os.path.join(rendezvous_dir(), "rccl_unique_id.bin")
 
     def bootstrap(uid):
-        box = [uid]
-        dist.broadcast_object_list(box, src=0)
-        return box[0]
-    return pkg.RcclComm(eng, rank, world, bootstrap)
+        if rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as fh:
+                fh.write(uid)
+            os.replace(tmp, path)
+            return uid
+        t_end = time.time() + 300
+        while time.time() < t_end:
+            try:
+                data = open(path, "rb").read()
+                if len(data) == 128:
+                    return data
+            except OSError:
+                pass
+            time.sleep(0.05)
+        raise RuntimeError(f"rank {rank}: no unique id at {path} after 300 s")
+    return bootstrap
+
+
+def make_comm(pkg, eng, rank, world):
+    """SingleComm, or the engine's RCCL communicator."""
+    if world == 1:
+        return pkg.SingleComm()
+    return pkg.RcclComm(eng, rank, world, bootstrap_via_file(rank))
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (same command line, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the env) BEFORE this process makes any GPU call - it never does - wait for them, hand rank
+    0's stdout through, return non-zero if any rank failed (the others are then terminated by pid)."""
+    rdzv = tempfile.mkdtemp(prefix="smc_bench_rdzv_")
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=os.environ.get("MASTER_PORT", "29500"), SMC_BENCH_RDZV=rdzv)
+            out = None if r == 0 else sys.stderr            # one JSON line on stdout: rank 0's
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+        rc = 0
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.1)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0:
+                    rc = code if code > 0 else 1
+        if rc != 0:                                          # a failed rank leaves its peers waiting in a collective
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            print(f"bench.py: a rank exited with status {rc}; the run is void", file=sys.stderr)
+        return rc
+    finally:
+        shutil.rmtree(rdzv, ignore_errors=True)
+
+
+def launch_check(rank, world):
+    """--launch-check: the rank plumbing without a GPU (tests/test_bench_contract.py): every rank obtains the 128 bytes rank 0
+    published; rank 0 prints one JSON line."""
+    fail_rank = os.environ.get("SMC_BENCH_FAIL_RANK")
+    if fail_rank is not None and int(fail_rank) == rank:
+        sys.exit(3)
+    uid = os.urandom(128) if rank == 0 else None
+    got = bootstrap_via_file(rank)(uid)
+    assert len(got) == 128
+    with open(os.path.join(rendezvous_dir(), f"seen_{rank}"), "w") as fh:
+        fh.write(hashlib.sha256(got).hexdigest())
+    if rank == 0:
+        t_end = time.time() + 60
+        seen = {}
+        while len(seen) < world and time.time() < t_end:
+            for r in range(world):
+                try:
+                    seen[r] = open(os.path.join(rendezvous_dir(), f"seen_{r}")).read()
+                except OSError:
+                    pass
+            time.sleep(0.05)
+        print(json.dumps({"launch_check": True, "world": world, "ranks_seen": sorted(seen),
+                          "same_id": len(set(seen.values())) == 1 and len(seen) == world}), flush=True)
+        if "SMC_BENCH_RDZV" not in os.environ:           # under torch.distributed.run nobody else removes it
+            shutil.rmtree(rendezvous_dir(), ignore_errors=True)
 
 
 def bench_methanation(args):
@@ -248,17 +380,18 @@ def main():
     ap.add_argument("--meth-sweeps", type=int, default=0,
                     help="methanation only: time this many Metropolis sweeps (and the initial likelihood sweep) instead "
                          "of whole runs - the mode for config 4's full size, --particles-per-gpu 100000")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.workload == "methanation":
-        return bench_methanation(args)
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # no launcher: become one (no GPU call in this process)
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    if args.launch_check:
+        return launch_check(rank, world)
+    if args.workload == "methanation":
+        return bench_methanation(args)
+    args.gpus = world
 
     pkg = entry.load_package()
     n_local = args.particles_per_gpu
@@ -302,9 +435,8 @@ def main():
         w_cov = s.w_cov()
         ts = time.perf_counter()
         n_ss = 10
-        for j in range(n_ss):
-            cov_m = pkg.proposal_cov(eng, comm, s, w_cov)
-            eng.mh_step_device_rng(1.0, 1.0, pkg.mvn_transform(cov_m), 424242, j, 0)
+        for j in range(n_ss):                  # the fused iteration run_smc uses: moments -> factor -> propose -> solve -> accept
+            eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 424242, j, 0)
         eng.synchronize()
         dt_ss = time.perf_counter() - ts
         tm_ss = eng.timing_get()
@@ -331,15 +463,9 @@ def main():
         ach_tflops = flop_per_launch / (solve_ms * 1e-3) / 1e12
         hbm_gbps = HBM_BYTES_PER_PARTICLE_SOLVE * n_local / (solve_ms * 1e-3) / 1e9
         ess_ms = timing["ess"]["ms"]
-        traffic = None
-        try:   # HBM bytes per launch of the solve kernel from the committed rocprofv3 --pmc passes (profiles/)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_fetch_write_summary.json")))
-            k = "void smc::mm_solve_kernel<false>"
-            # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes fetched
-            # (MI355X_MICROARCH.md, HBM section; confirmed here on mm_propose_kernel: 11.8 MiB reported for 24 MB read)
-            traffic = (2 * pmc["pmc_fetch"][k]["avg_counter_value"] + pmc["pmc_write"][k]["avg_counter_value"]) * 1024
-        except Exception:
-            pass
+        traffic, traffic_note = measured_traffic("void smc::mm_solve_kernel<false>", n_local)
+        ess_l = timing["ess"]["launches"]
+        ess_avg_ms = ess_ms / max(1, ess_l)
         result = {
             "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -361,9 +487,8 @@ def main():
                                        "MFMA is unused); on MI355X the FP64 matrix and vector peaks coincide (78.6 TFLOP/s), "
                                        "which is the `peak` below; the HBM side is in `hbm`",
                          "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this "
-                                         "command (profiles/r01_c_pmc_fetch_write_summary.json), FETCH_SIZE doubled",
+                         "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel_source_sha": kernel_source_sha(),
                          "peak_measured_fp64_fma_tflops": 57.3,
                          "avg_launch_ms": solve_ms, "launches": sv["launches"], "mh_sweep_avg_ms": mh_ms,
                          "algorithmic_flop_per_launch": flop_per_launch,
@@ -371,15 +496,24 @@ def main():
                                  "achieved_GBps": hbm_gbps, "peak_GBps": HBM_PEAK_GBPS,
                                  "frac": hbm_gbps / HBM_PEAK_GBPS},
                          "mfma": "unused (largest contraction is 3x3)"},
+            # the ESS-search half of BASELINE.json's metric has its own kernel and its own bound: one pass over lk (8 B per
+            # particle) evaluates up to 16 tempering candidates = 16 exp + 32 FMA per 8 B, so the pass is exp-bound, not
+            # HBM-bound (an 8 MB read would take ~1.3 us at the HBM roof)
+            "ess_roofline": {"kernel": "ess_partial_kernel<K> + sum_rows_final_kernel (one fused pass for K <= 16 candidates)",
+                             "bound": "FP64 exp throughput (K exp per 8 B read); HBM side reported",
+                             "avg_launch_ms": ess_avg_ms, "launches": ess_l, "candidates_per_launch": ess_iters / max(1, ess_l),
+                             "algorithmic_bytes_per_launch": 8 * n_local,
+                             "achieved_GBps": 8 * n_local / (ess_avg_ms * 1e-3) / 1e9 if ess_avg_ms > 0 else None,
+                             "peak_GBps": HBM_PEAK_GBPS,
+                             "exp_per_s": (ess_iters * n_local) / (ess_ms * 1e-3) if ess_ms > 0 else None},
         }
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)
     comm.barrier()
     eng.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if world > 1 and rank == 0:                       # everybody is past the last collective: the id file has served
+        shutil.rmtree(rendezvous_dir(), ignore_errors=True)
 
 
 if __name__ == "__main__":

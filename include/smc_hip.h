@@ -159,6 +159,11 @@ int smc_max_lk_local(smc_ctx *ctx, double *max_lk);
 /* For k < n_cand: sum_w[k] = sum_i exp((lk_i-max_lk)*gm[k]), sum_w2[k] = sum_i exp(...)^2 over this
  * rank's block (Micmem_SMC_main.py:118,124-134; ess = sum_w^2 / sum_w2 / N).  n_cand <= SMC_MAX_ESS_CAND. */
 int smc_ess_partials(smc_ctx *ctx, double max_lk, const double *gm, int n_cand, double *sum_w, double *sum_w2);
+/* The same two reductions over ALL ranks: the partial stays on the device, RCCL reduces it
+ * in place on the context's stream (allreduce MAX of 1 f64 / SUM of 2 n_cand f64) and ONE read-back follows - no
+ * device->host->device->host round trip per collective.  With one rank (no communicator) they equal the calls above. */
+int smc_max_lk_global(smc_ctx *ctx, double *max_lk);
+int smc_ess_partials_global(smc_ctx *ctx, double max_lk, const double *gm, int n_cand, double *sum_w, double *sum_w2);
 
 /* ---- A5: residual-systematic resampling (Micmem_SMC_main.py:147-184) ------------------------ */
 /* Phase 1: with w_i = exp((lk_i-max_lk)*gm)/sum_weight_global, p_is_i = trunc(w_i*N_global) and the
@@ -179,6 +184,12 @@ int smc_download_offspring(smc_ctx *ctx, int64_t *p_is, int64_t n);
  * Slots >= total offspring keep the content the reference's persistent p_filt would hold
  * (zeros before the first tempering step, the previous p_pred row afterwards). */
 int smc_resample_phase3(smc_ctx *ctx, const int64_t *out_base_all, const int64_t *offspring_all, int first_step);
+/* Micmem_SMC_main.py:147-184 across all ranks in one call: phase 1 -> all-gather of (residual sum, integer copies) ->
+ * residual prefix of the lower ranks as a running sum in rank order (:165-167) -> phase 2 -> all-gather of the offspring
+ * counts -> phase 3.  Two synchronisations instead of six.  n_offspring = sum of p_is over all particles (== N unless the
+ * reference's stale-row case, :178-184, occurs), count_sum = sum of trunc(w*N) (the reference prints N - count_sum as n_tmp). */
+int smc_resample_global(smc_ctx *ctx, double max_lk, double gm, double sum_weight_global, double wrand, int first_step,
+                        int64_t *n_offspring, int64_t *count_sum);
 
 /* ---- A6: proposal covariance (np.cov(p_filt.T, bias=True), Micmem_SMC_main.py:212) ---------- */
 /* sums[d] = sum_i theta_i over this rank's SMC_SET_FILT block. */
@@ -201,6 +212,21 @@ int smc_mh_step_host_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const 
 int smc_mh_step_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *transform, uint64_t seed,
                            uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
                            int64_t *n_failed, int64_t *rk_attempts);
+/* One whole Metropolis iteration of the device-RNG mode on the stream (Micmem_SMC_main.py:212-241), every rank calling it
+ * together: cov_m = np.cov(p_filt.T, bias=True) * w_cov from device-side moments all-reduced in place (:212-215), the factor
+ * NumPy's legacy multivariate_normal multiplies standard normals with - (u,s,v) = svd(cov_m), sqrt(s)[:,None]*v - computed on
+ * the device (cov_m is symmetric: a Jacobi eigen-decomposition, |lambda| sorted descending, largest component of each row
+ * positive), then proposal, support mask, likelihood, accept/select as in smc_mh_step_device_rng, then the accept counts
+ * summed over the ranks.  One synchronisation.  w_cov: d x d (Micmem_settings.py:94-97).  accepted_now, accepted_ever and
+ * n_failed are totals over ALL ranks, rk_attempts_local is this rank's; cov_m (optional, d x d) receives the global cov_m. */
+int smc_mh_iteration_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed,
+                                uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
+                                int64_t *n_failed, int64_t *rk_attempts_local, double *cov_m);
+/* The first half of that iteration on its own (no model needed): cov_m = np.cov(p_filt.T, bias=True) * w_cov over all ranks
+ * (:212-215) and the factor sqrt(s)[:,None]*v of its SVD, both d x d row-major; either output may be NULL. */
+int smc_proposal_factor_device(smc_ctx *ctx, const double *w_cov, double *cov_m, double *transform);
+/* The d x d factor (row-major) the last smc_mh_iteration_device_rng drew its proposals with. */
+int smc_mh_iteration_last_transform(smc_ctx *ctx, double *transform);
 /* r_ac = zeros (Micmem_SMC_main.py:187). */
 int smc_reset_accept_flags(smc_ctx *ctx);
 /* Copies of the last proposals/lk2 for parity tests (valid after an MH step when enabled). */

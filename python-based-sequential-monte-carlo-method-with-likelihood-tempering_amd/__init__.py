@@ -5,12 +5,12 @@ loaded by path: `__graft_entry__.load_package()` registers it as the module `smc
 
   binding   ctypes declarations of include/smc_hip.h
   engine    HipEngine: one libsmc_hip.so context (device-resident particle sets + stages)
-  comm      SingleComm / RcclComm / TorchDistComm
+  comm      SingleComm / RcclComm
   driver    SMCSettings, run_smc: the tempering loop of the reference's driver scripts
   dropin/   shadow modules with the reference's names (Micmem_settings, Micmem_likelihood)
 """
 from .binding import (SMC_SET_FILT, SMC_SET_PRED, SmcError, header_symbols, lib, LIB_PATH)  # noqa: F401
-from .comm import RcclComm, SingleComm, TorchDistComm  # noqa: F401
+from .comm import RcclComm, SingleComm  # noqa: F401
 from .driver import SMCSettings, ess_candidates, ess_search, mvn_transform, proposal_cov, resample, run_smc, sample_prior  # noqa: F401
 from .engine import HipEngine  # noqa: F401
 from . import methanation  # noqa: F401

@@ -64,6 +64,12 @@ SIGNATURES = {
     "smc_mm_loglik_host": (cint, [c_ctx, c_dp, i64, c_dp, c_dp, c_i64p, c_i64p]),
     "smc_max_lk_local": (cint, [c_ctx, c_dp]),
     "smc_ess_partials": (cint, [c_ctx, f64, c_dp, cint, c_dp, c_dp]),
+    "smc_max_lk_global": (cint, [c_ctx, c_dp]),
+    "smc_ess_partials_global": (cint, [c_ctx, f64, c_dp, cint, c_dp, c_dp]),
+    "smc_resample_global": (cint, [c_ctx, f64, f64, f64, f64, cint, c_i64p, c_i64p]),
+    "smc_mh_iteration_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, i64, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
+    "smc_mh_iteration_last_transform": (cint, [c_ctx, c_dp]),
+    "smc_proposal_factor_device": (cint, [c_ctx, c_dp, c_dp, c_dp]),
     "smc_resample_phase1": (cint, [c_ctx, f64, f64, f64, c_dp, c_i64p]),
     "smc_resample_phase2": (cint, [c_ctx, f64, f64, f64, f64, f64, c_i64p]),
     "smc_download_offspring": (cint, [c_ctx, c_i64p, i64]),

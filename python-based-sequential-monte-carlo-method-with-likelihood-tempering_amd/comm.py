@@ -7,8 +7,8 @@ scalars per call) plus the particle exchange after resampling, which the engine 
   SingleComm      one rank, no communication
   RcclComm        the engine's own RCCL communicator (ncclAllReduce / ncclAllGather over xGMI) - the
                   product path for N > 1 GPUs
-  TorchDistComm   torch.distributed on CPU tensors (gloo) - lets the sharded driver logic be tested
-                  with world_size 2 on a machine without GPUs; never selected automatically
+Host-side communicators used only by the tests (threads on one GPU, gloo on CPUs) live in tests/; they lack
+`on_device`, so the driver composes the engine's *_local calls with their reductions.
 """
 from __future__ import annotations
 
@@ -17,6 +17,7 @@ import numpy as np
 
 class SingleComm:
     rank, size = 0, 1
+    on_device = True      # nothing to reduce: the engine's *_global entry points are the whole story
 
     def allreduce_sum(self, x):
         return np.array(x, dtype=np.float64, copy=True)
@@ -44,6 +45,8 @@ class RcclComm:
     (bench.py does this with torch.distributed's store; any out-of-band channel works).
     """
 
+    on_device = True      # reductions run inside the engine: RCCL in place on its stream (driver._on_device)
+
     def __init__(self, engine, rank: int, size: int, bootstrap):
         self.engine, self.rank, self.size = engine, int(rank), int(size)
         uid = engine.comm_get_unique_id() if rank == 0 else None
@@ -67,42 +70,3 @@ class RcclComm:
 
     def barrier(self):
         self.engine.comm_barrier()
-
-
-class TorchDistComm:
-    """torch.distributed (already initialised by the caller, e.g. gloo) on CPU tensors."""
-
-    def __init__(self):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.size = dist.get_rank(), dist.get_world_size()
-
-    def _allreduce(self, x, dtype, op):
-        t = self.torch.from_numpy(np.array(np.atleast_1d(x), dtype=dtype, copy=True))
-        self.dist.all_reduce(t, op=op)
-        return t.numpy()
-
-    def allreduce_sum(self, x):
-        return self._allreduce(x, np.float64, self.dist.ReduceOp.SUM)
-
-    def allreduce_max(self, x):
-        return self._allreduce(x, np.float64, self.dist.ReduceOp.MAX)
-
-    def allreduce_sum_i64(self, x):
-        return self._allreduce(x, np.int64, self.dist.ReduceOp.SUM)
-
-    def _allgather(self, x, dtype):
-        t = self.torch.from_numpy(np.array(np.atleast_1d(x), dtype=dtype, copy=True))
-        outs = [self.torch.empty_like(t) for _ in range(self.size)]
-        self.dist.all_gather(outs, t)
-        return np.stack([o.numpy() for o in outs])
-
-    def allgather(self, x):
-        return self._allgather(x, np.float64)
-
-    def allgather_i64(self, x):
-        return self._allgather(x, np.int64)
-
-    def barrier(self):
-        self.dist.barrier()

@@ -143,9 +143,10 @@ generic_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt
             g[2 * b] = rad * cs;
             if (2 * b + 1 < SMC_MAX_DIM) g[2 * b + 1] = rad * sn;
         }
+        const double *T = mh.transform_dev ? mh.transform_dev : mh.transform;
         for (int c = 0; c < d; ++c) {
             double s = 0.0;
-            for (int kq = 0; kq < d; ++kq) s += g[kq] * mh.transform[kq * d + c];
+            for (int kq = 0; kq < d; ++kq) s += g[kq] * T[kq * d + c];
             z[c] = s;
         }
     } else {

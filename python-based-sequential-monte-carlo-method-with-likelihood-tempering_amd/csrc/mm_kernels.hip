@@ -55,7 +55,7 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
         sincos(6.283185307179586 * ub, &sa, &ca);
         const double g0 = ra_ * ca, g1 = ra_ * sa, g2 = rc_ * cos(6.283185307179586 * ud);
         // x = z @ transform  (NumPy multivariate_normal: z @ (sqrt(s)[:,None]*v))
-        const double *T = mh.transform;
+        const double *T = mh.transform_dev ? mh.transform_dev : mh.transform;
         z0 = g0 * T[0] + g1 * T[3] + g2 * T[6];
         z1 = g0 * T[1] + g1 * T[4] + g2 * T[7];
         z2 = g0 * T[2] + g1 * T[5] + g2 * T[8];

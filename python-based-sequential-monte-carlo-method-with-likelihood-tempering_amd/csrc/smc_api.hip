@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -583,6 +584,110 @@ int smc_ess_partials(smc_ctx *c, double max_lk, const double *gm, int n_cand, do
     return 0;
 }
 
+// ---- reductions over ALL ranks: kernel -> ncclAllReduce on the device buffer -> ONE read-back ----------------
+// (the *_local calls above return this rank's partial and leave the reduction to a host-side communicator: three PCIe
+// hops per collective; these keep the partial on the device)
+}  // extern "C"
+static int dev_allreduce(smc_ctx *c, void *buf, size_t n, ncclDataType_t dt, ncclRedOp_t op) {
+    if (!c->nccl_comm) {
+        if (c->world > 1) return fail(c, "world > 1 but smc_comm_init has not been called (the *_global entry points need RCCL)");
+        return 0;
+    }
+    NCCLC(c, ncclAllReduce(buf, buf, n, dt, op, (ncclComm_t)c->nccl_comm, c->stream));
+    return 0;
+}
+// all-gather of n 8-byte words per rank from d_small[0..n) into d_small[2048 ..), then to h_small[0 .. n*world)
+static int dev_allgather_words(smc_ctx *c, int n) {
+    if ((size_t)n * c->world > 2048) return fail(c, "collective payload too large");
+    if (!c->nccl_comm) {
+        if (c->world > 1) return fail(c, "world > 1 but smc_comm_init has not been called (the *_global entry points need RCCL)");
+        HIPC(c, hipMemcpyAsync(c->h_small, c->d_small, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        NCCLC(c, ncclAllGather(c->d_small, c->d_small + 2048, (size_t)n, ncclUint64, (ncclComm_t)c->nccl_comm, c->stream));
+        HIPC(c, hipMemcpyAsync(c->h_small, c->d_small + 2048, (size_t)n * c->world * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" {
+
+int smc_max_lk_global(smc_ctx *c, double *max_lk) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_MAX);
+        launch_max(c, c->set[SMC_SET_PRED].lk, c->n_local, c->d_small);
+    }
+    HIPC(c, hipGetLastError());
+    if (dev_allreduce(c, c->d_small, 1, ncclDouble, ncclMax)) return 1;
+    if (fetch_small(c, 1)) return 1;
+    *max_lk = c->h_small[0];
+    return 0;
+}
+
+int smc_ess_partials_global(smc_ctx *c, double max_lk, const double *gm, int n_cand, double *sum_w, double *sum_w2) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (n_cand < 1 || n_cand > SMC_MAX_ESS_CAND) return fail(c, "n_cand out of range");
+    HIPC(c, hipSetDevice(c->device));
+    {
+        ScopedTimer tm(c, SMC_T_ESS);
+        launch_ess(c, c->set[SMC_SET_PRED].lk, c->n_local, max_lk, gm, n_cand, c->d_small);
+    }
+    HIPC(c, hipGetLastError());
+    const int nv = 2 * ess_padded_k(n_cand);
+    if (dev_allreduce(c, c->d_small, (size_t)nv, ncclDouble, ncclSum)) return 1;
+    if (fetch_small(c, nv)) return 1;
+    for (int k = 0; k < n_cand; ++k) {
+        sum_w[k] = c->h_small[2 * k];
+        sum_w2[k] = c->h_small[2 * k + 1];
+    }
+    return 0;
+}
+
+int smc_resample_global(smc_ctx *c, double max_lk, double gm, double sum_weight_global, double wrand, int first_step,
+                        int64_t *n_offspring, int64_t *count_sum) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    const int W = c->world, R = c->rank;
+    // 1. residual sums and integer copies of this rank; every rank learns all of them
+    {
+        ScopedTimer tm(c, SMC_T_RESAMPLE);
+        launch_resample_phase1(c, max_lk, gm, sum_weight_global);
+        HIPC(c, hipMemcpyAsync(c->d_small, c->d_blk_r + c->n_tiles, 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->d_small + 1, c->d_blk_c + c->n_tiles, 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPC(c, hipGetLastError());
+    if (dev_allgather_words(c, 2)) return 1;
+    double prefix = 0.0;                     // running sum in rank order, as the sequential loop would form it (:165-167)
+    int64_t csum = 0;
+    for (int q = 0; q < W; ++q) {
+        int64_t cq;
+        memcpy(&cq, c->h_small + 2 * q + 1, sizeof cq);
+        csum += cq;
+        if (q < R) prefix = prefix + c->h_small[2 * q];
+    }
+    // 2. offspring of this rank given the residual mass below it; every rank learns all counts
+    {
+        ScopedTimer tm(c, SMC_T_RESAMPLE);
+        launch_resample_phase2(c, max_lk, gm, sum_weight_global, prefix, wrand);
+        HIPC(c, hipMemcpyAsync(c->d_small, c->d_blk_c + c->n_tiles, 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPC(c, hipGetLastError());
+    if (dev_allgather_words(c, 1)) return 1;
+    std::vector<int64_t> o_all(W), bases(W);
+    int64_t tot = 0;
+    for (int q = 0; q < W; ++q) {
+        memcpy(&o_all[q], c->h_small + q, sizeof(int64_t));
+        bases[q] = tot;
+        tot += o_all[q];
+    }
+    // 3. gather + exchange
+    if (smc_resample_phase3(c, bases.data(), o_all.data(), first_step)) return 1;
+    if (n_offspring) *n_offspring = tot;
+    if (count_sum) *count_sum = csum;
+    return 0;
+}
+
 // ---- resampling ------------------------------------------------------------------------------------
 int smc_resample_phase1(smc_ctx *c, double max_lk, double gm, double sum_weight_global, double *residual_sum_local,
                         int64_t *count_sum_local) {
@@ -921,6 +1026,96 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
         if (c->model_kind == 2) launch_meth_mh(c, c->n_local, mh); else if (c->model_kind == 3) launch_user_mh(c, c->n_local, mh); else launch_mm_mh(c, c->n_local, mh);
     }
     return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
+}
+
+// One Metropolis iteration of the device-RNG mode with everything on the stream (Micmem_SMC_main.py:212-241):
+//   column sums -> [allreduce] -> centred sums about the global mean -> [allreduce] -> cov_m = cov * w_cov and its
+//   multivariate_normal factor (one thread) -> propose -> solve -> accept/select -> counters -> [allreduce] -> ONE read-back.
+// d_small layout: [0, d) sums | [16, 16 + d(d+1)/2) centred sums | [64, 64 + d*d) cov_m | [128, 128 + d*d) factor |
+// [256, 260) counters summed over the ranks.
+int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed,
+                                uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
+                                int64_t *n_failed, int64_t *rk_attempts_local, double *cov_m) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
+    if (!w_cov) return fail(c, "smc_mh_iteration_device_rng: w_cov is NULL");
+    HIPC(c, hipSetDevice(c->device));
+    const int d = c->dim, npair = d * (d + 1) / 2;
+    double *d_sums = c->d_small, *d_cent = c->d_small + 16, *d_cov = c->d_small + 64, *d_xf = c->d_small + 128;
+    unsigned long long *d_tot = (unsigned long long *)(c->d_small + 256);
+    {
+        ScopedTimer tm(c, SMC_T_MOMENTS);
+        launch_moment_sums(c, d_sums);
+        if (dev_allreduce(c, d_sums, (size_t)d, ncclDouble, ncclSum)) return 1;
+        launch_moment_centered_dev(c, d_sums, d_cent);
+        if (dev_allreduce(c, d_cent, (size_t)npair, ncclDouble, ncclSum)) return 1;
+        launch_mh_transform(c, d_cent, w_cov, d_cov, d_xf);
+    }
+    if (counters_begin(c)) return 1;
+    MHParams mh{};
+    mh.gamma = gamma;
+    mh.ratio = mhstep_ratio;
+    mh.device_rng = 1;
+    mh.prior_mode = c->prior_mode;
+    mh.pratio = c->d_pratio;
+    mh.seed = seed;
+    mh.stream = stream;
+    mh.global_offset = global_offset;
+    mh.transform_dev = d_xf;
+    {
+        ScopedTimer tm(c, SMC_T_MH);
+        if (c->model_kind == 2) launch_meth_mh(c, c->n_local, mh); else if (c->model_kind == 3) launch_user_mh(c, c->n_local, mh); else launch_mm_mh(c, c->n_local, mh);
+    }
+    HIPC(c, hipGetLastError());
+    if (c->launch_failed) { c->launch_failed = false; return 1; }
+    // n_failed, rk_attempts, accepted_now, accepted_ever are the first four words of SweepCounters
+    static_assert(offsetof(SweepCounters, accepted_ever) == 24, "SweepCounters layout");
+    HIPC(c, hipMemcpyAsync(d_tot, c->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    if (dev_allreduce(c, d_tot, 4, ncclUint64, ncclSum)) return 1;
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small + 64, (size_t)(256 + 4 - 64) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (counters_end(c)) return 1;      // local counters + the one synchronisation of the iteration
+    unsigned long long tot[4];
+    memcpy(tot, c->h_small + (256 - 64), sizeof tot);
+    if (n_failed) *n_failed = (int64_t)tot[0];
+    if (accepted_now) *accepted_now = (int64_t)tot[2];
+    if (accepted_ever) *accepted_ever = (int64_t)tot[3];
+    if (rk_attempts_local) *rk_attempts_local = (int64_t)c->h_counters->rk_attempts;
+    if (cov_m)
+        for (int i = 0; i < d * d; ++i) cov_m[i] = c->h_small[i];
+    return 0;
+}
+
+// Stage A6 + the factor of A7 alone, over all ranks: cov_m and its multivariate_normal factor from the FILT set (no model
+// needed) - the first half of smc_mh_iteration_device_rng with a read-back.
+int smc_proposal_factor_device(smc_ctx *c, const double *w_cov, double *cov_m, double *transform) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!w_cov) return fail(c, "smc_proposal_factor_device: w_cov is NULL");
+    HIPC(c, hipSetDevice(c->device));
+    const int d = c->dim, npair = d * (d + 1) / 2;
+    double *d_sums = c->d_small, *d_cent = c->d_small + 16, *d_cov = c->d_small + 64, *d_xf = c->d_small + 128;
+    {
+        ScopedTimer tm(c, SMC_T_MOMENTS);
+        launch_moment_sums(c, d_sums);
+        if (dev_allreduce(c, d_sums, (size_t)d, ncclDouble, ncclSum)) return 1;
+        launch_moment_centered_dev(c, d_sums, d_cent);
+        if (dev_allreduce(c, d_cent, (size_t)npair, ncclDouble, ncclSum)) return 1;
+        launch_mh_transform(c, d_cent, w_cov, d_cov, d_xf);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small + 64, (size_t)(128 + 64) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < d * d; ++i) {
+        if (cov_m) cov_m[i] = c->h_small[i];
+        if (transform) transform[i] = c->h_small[64 + i];
+    }
+    return 0;
+}
+
+// the d x d factor the last smc_mh_iteration_device_rng drew its proposals with (row-major; debugging / tests)
+int smc_mh_iteration_last_transform(smc_ctx *c, double *transform) {
+    if (!c) return fail(nullptr, "NULL context");
+    for (int i = 0; i < c->dim * c->dim; ++i) transform[i] = c->h_small[(128 - 64) + i];
+    return 0;
 }
 
 int smc_set_debug_capture(smc_ctx *c, int enable) {

@@ -55,6 +55,7 @@ struct MHParams {    // passed by value to the fused MH kernel
     const double *noise;  // host-RNG mode: SoA d x n (device); nullptr in device-RNG mode
     const double *rr;     // host-RNG mode: n uniforms (device)
     double transform[SMC_MAX_DIM * SMC_MAX_DIM];  // device-RNG mode: z @ transform
+    const double *transform_dev;  // if set: the same d x d factor in device memory (fused iteration), read instead
     uint64_t seed, stream;
     int64_t global_offset;
     int device_rng;

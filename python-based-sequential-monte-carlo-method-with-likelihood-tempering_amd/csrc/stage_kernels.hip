@@ -212,12 +212,17 @@ __global__ void __launch_bounds__(kScanBlock) moment_sum_kernel(const double *__
 struct MeanArg {
     double m[SMC_MAX_DIM];
 };
+// dev_sums != nullptr: the mean is formed on the device from the (already all-reduced) column sums, X.mean(axis=1) =
+// sum / N - the fused Metropolis iteration (smc_mh_iteration_device_rng) never takes the sums to the host
 __global__ void __launch_bounds__(kScanBlock) moment_centered_kernel(const double *__restrict__ theta, int64_t stride,
                                                                      int64_t n, int d, MeanArg mean,
+                                                                     const double *__restrict__ dev_sums, double n_div,
                                                                      double *__restrict__ partials) {
     __shared__ double lds[4];
     double acc[SMC_MAX_DIM * (SMC_MAX_DIM + 1) / 2];
     const int npair = d * (d + 1) / 2;
+    if (dev_sums)
+        for (int c = 0; c < d; ++c) mean.m[c] = dev_sums[c] / n_div;
     for (int k = 0; k < npair; ++k) acc[k] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double x[SMC_MAX_DIM];
@@ -229,6 +234,88 @@ __global__ void __launch_bounds__(kScanBlock) moment_centered_kernel(const doubl
     for (int k = 0; k < npair; ++k) {
         const double s = block_sum(acc[k], lds);
         if (threadIdx.x == 0) partials[(size_t)blockIdx.x * npair + k] = s;
+    }
+}
+
+// cov_m = np.cov(p_filt.T, bias=True) * w_cov (Micmem_SMC_main.py:212-215) and the factor NumPy's legacy
+// multivariate_normal multiplies standard normals with (:220): (u, s, v) = svd(cov_m); x = z @ (sqrt(s)[:, None] * v).
+// cov_m is symmetric, so its SVD is its eigen-decomposition with s = |lambda| (sorted descending) and the rows of v the
+// eigenvectors: a cyclic Jacobi iteration in ONE thread (d <= 8: a few hundred flops, against a sweep of >= 1 ms).
+// Row signs are fixed by making the largest component of every row positive (LAPACK's are arbitrary; the distribution of
+// z @ A does not depend on them).  Pinned against driver.mvn_transform in tests/test_gpu_parity.py.
+struct WCov {
+    double w[SMC_MAX_DIM * SMC_MAX_DIM];
+};
+__global__ void mh_transform_kernel(const double *__restrict__ cent /* d(d+1)/2 centred sums, row-major upper */,
+                                    double n_global, WCov wcov, int d, double *__restrict__ cov_out,
+                                    double *__restrict__ xform_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double A[SMC_MAX_DIM][SMC_MAX_DIM], V[SMC_MAX_DIM][SMC_MAX_DIM];
+    const double inv_n = 1.0 / n_global;     // np.true_divide(1, fact), then c *= that (np.cov)
+    int k = 0;
+    for (int a = 0; a < d; ++a)
+        for (int b = a; b < d; ++b) {
+            const double v = cent[k++] * inv_n;
+            A[a][b] = v * wcov.w[a * d + b];
+            A[b][a] = v * wcov.w[b * d + a];
+        }
+    for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) {
+            cov_out[a * d + b] = A[a][b];
+            V[a][b] = (a == b) ? 1.0 : 0.0;
+        }
+    // w_cov is symmetric in the reference (Micmem_settings.py:94-97); should a caller pass an asymmetric one, the
+    // decomposition below is that of the symmetric part
+    for (int a = 0; a < d; ++a)
+        for (int b = a + 1; b < d; ++b) A[a][b] = A[b][a] = 0.5 * (A[a][b] + A[b][a]);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int p = 0; p < d; ++p) {
+            diag += A[p][p] * A[p][p];
+            for (int q = p + 1; q < d; ++q) off += A[p][q] * A[p][q];
+        }
+        if (!(off > 1e-34 * diag)) break;   // also leaves on NaN
+        for (int p = 0; p < d; ++p)
+            for (int q = p + 1; q < d; ++q) {
+                const double apq = A[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int r = 0; r < d; ++r) {   // A <- A J
+                    const double arp = A[r][p], arq = A[r][q];
+                    A[r][p] = cs * arp - sn * arq;
+                    A[r][q] = sn * arp + cs * arq;
+                }
+                for (int r = 0; r < d; ++r) {   // A <- J^T A
+                    const double apr = A[p][r], aqr = A[q][r];
+                    A[p][r] = cs * apr - sn * aqr;
+                    A[q][r] = sn * apr + cs * aqr;
+                }
+                for (int r = 0; r < d; ++r) {
+                    const double vrp = V[r][p], vrq = V[r][q];
+                    V[r][p] = cs * vrp - sn * vrq;
+                    V[r][q] = sn * vrp + cs * vrq;
+                }
+            }
+    }
+    int order[SMC_MAX_DIM];
+    for (int i = 0; i < d; ++i) order[i] = i;
+    for (int i = 0; i < d; ++i)          // selection sort by |lambda| descending (svd order)
+        for (int j = i + 1; j < d; ++j)
+            if (fabs(A[order[j]][order[j]]) > fabs(A[order[i]][order[i]])) {
+                const int t = order[i];
+                order[i] = order[j];
+                order[j] = t;
+            }
+    for (int i = 0; i < d; ++i) {
+        const int e = order[i];
+        const double sv = sqrt(fabs(A[e][e]));
+        int big = 0;
+        for (int c = 1; c < d; ++c)
+            if (fabs(V[c][e]) > fabs(V[big][e])) big = c;
+        const double sg = (V[big][e] < 0.0) ? -1.0 : 1.0;
+        for (int c = 0; c < d; ++c) xform_out[i * d + c] = sv * (sg * V[c][e]);
     }
 }
 
@@ -557,8 +644,23 @@ void launch_moment_centered(smc_ctx *c, const double *mean, double *d_out) {
     const int g = reduce_grid(c->n_local);
     const int npair = c->dim * (c->dim + 1) / 2;
     hipLaunchKernelGGL(moment_centered_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, F.theta, F.stride, c->n_local,
-                       c->dim, m, c->d_partials);
+                       c->dim, m, (const double *)nullptr, 1.0, c->d_partials);
     hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
+}
+void launch_moment_centered_dev(smc_ctx *c, const double *d_sums, double *d_out) {
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    MeanArg m{};
+    const int g = reduce_grid(c->n_local);
+    const int npair = c->dim * (c->dim + 1) / 2;
+    hipLaunchKernelGGL(moment_centered_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, F.theta, F.stride, c->n_local,
+                       c->dim, m, d_sums, (double)c->n_global, c->d_partials);
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
+}
+void launch_mh_transform(smc_ctx *c, const double *d_cent, const double *w_cov, double *d_cov, double *d_xform) {
+    WCov w{};
+    for (int i = 0; i < c->dim * c->dim; ++i) w.w[i] = w_cov[i];
+    hipLaunchKernelGGL(mh_transform_kernel, dim3(1), dim3(64), 0, c->stream, d_cent, (double)c->n_global, w, c->dim, d_cov,
+                       d_xform);
 }
 
 static ResampleArgs make_args(smc_ctx *c, double max_lk, double gm, double sum_w, double wrand, double base) {

@@ -105,10 +105,32 @@ def ess_candidates(gamma_old: float, s: SMCSettings):
     return gms, gammas, gamma_new
 
 
+def _on_device(comm) -> bool:
+    """True when the communicator's reductions can run inside the engine (one rank, or the engine's own RCCL communicator):
+    the driver then calls the *_global entry points - partials stay on the device, RCCL reduces them in place on the
+    engine's stream, one read-back per stage.  Host-side communicators (tests) get the *_local calls + their own reduce."""
+    return bool(getattr(comm, "on_device", False))
+
+
+def _max_lk(engine, comm):
+    if _on_device(comm):
+        return float(engine.max_lk_global())
+    return float(comm.allreduce_max([engine.max_lk_local()])[0])
+
+
+def _ess_sums(engine, comm, max_lk, gms):
+    """sum_w[k], sum_w2[k] over ALL particles for the candidate increments gms."""
+    if _on_device(comm):
+        return engine.ess_partials_global(max_lk, gms)
+    sw, sw2 = engine.ess_partials(max_lk, gms)
+    tot = comm.allreduce_sum(np.concatenate([sw, sw2]))
+    return tot[:len(gms)], tot[len(gms):]
+
+
 def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_MAX_ESS_CAND):
     """main:111-144.  Candidates are evaluated `chunk` at a time by one fused pass over lk each."""
     n = s.n_particle
-    max_lk = float(comm.allreduce_max([engine.max_lk_local()])[0])            # :116
+    max_lk = _max_lk(engine, comm)                                            # :116
     if s.ess_search == "bisection":
         return ess_bisection(engine, comm, gamma_old, s, max_lk, chunk)
     gms, gammas, gamma_after_all = ess_candidates(gamma_old, s)
@@ -118,10 +140,8 @@ def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_
     k0 = 0
     while k0 < len(gms):
         part = gms[k0:k0 + chunk]
-        sw, sw2 = engine.ess_partials(max_lk, part)
+        sw, sw2 = _ess_sums(engine, comm, max_lk, part)
         launches += 1
-        tot = comm.allreduce_sum(np.concatenate([sw, sw2]))
-        sw, sw2 = tot[:len(part)], tot[len(part):]
         for i in range(len(part)):
             sum_w = float(sw[i])
             ess = 1.0 / (float(sw2[i]) / (sum_w * sum_w)) / n                 # :130-134
@@ -146,11 +166,9 @@ def ess_bisection(engine, comm, gamma_old: float, s: SMCSettings, max_lk: float,
     state = {"iters": 0, "launches": 0}
 
     def evaluate(gms):
-        sw, sw2 = engine.ess_partials(max_lk, list(gms))
+        sw, sw2 = _ess_sums(engine, comm, max_lk, list(gms))
         state["launches"] += 1
         state["iters"] += len(gms)
-        tot = comm.allreduce_sum(np.concatenate([sw, sw2]))
-        sw, sw2 = tot[:len(gms)], tot[len(gms):]
         return sw, 1.0 / (sw2 / (sw * sw)) / n
 
     sw, ess = evaluate([hi_gm])
@@ -181,6 +199,9 @@ def resample(engine, comm, es: dict, wrand_u: float, s: SMCSettings, first_step:
     """main:147-184 across ranks: residual sums -> prefix; offspring -> output slot bases; gather/exchange."""
     inv_Np = 1 / s.n_particle                                                 # Micmem_settings.py:17
     wrand = wrand_u * inv_Np                                                  # :156
+    if _on_device(comm):                                                      # all three phases + their all-gathers in the engine
+        r = engine.resample_global(es["max_lk"], es["gm"], es["sum_weight"], wrand, first_step)
+        return {"n_offspring": r["n_offspring"], "n_tmp_before": s.n_particle - r["count_sum"]}
     r_loc, c_loc = engine.resample_phase1(es["max_lk"], es["gm"], es["sum_weight"])
     r_all = comm.allgather([r_loc])[:, 0]
     prefix = 0.0
@@ -351,20 +372,27 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         j = 0
         acc_ever = 0
         mh_log = []
+        fused = rng == "device" and _on_device(comm)
         for j in range(nMH):                                                  # :209
-            cov_m = proposal_cov(engine, comm, s, w_cov)                      # :212-215
-            if rng == "numpy":
-                noise = np.random.multivariate_normal(np.zeros(d), cov_m, n)  # :220
-                rr = np.random.uniform(0, 1, n)                               # :235
-                out = engine.mh_step_host_rng(gamma_new, mhstep_ratio, noise[lo:lo + n_local], rr[lo:lo + n_local])
+            if fused:                                                         # :212-241 in one call, one synchronisation
+                out = engine.mh_iteration_device_rng(gamma_new, mhstep_ratio, w_cov, seed_device, (step << 16) | j, lo)
+                cov_m = out["cov_m"]
+                tot = [out["accepted_ever"], out["accepted_now"], out["n_failed"]]     # already summed over the ranks
+                out = dict(out, n_failed=0)                                   # account() counts this rank's share only once
             else:
-                out = engine.mh_step_device_rng(gamma_new, mhstep_ratio, mvn_transform(cov_m), seed_device,
-                                                (step << 16) | j, lo)
+                cov_m = proposal_cov(engine, comm, s, w_cov)                  # :212-215
+                if rng == "numpy":
+                    noise = np.random.multivariate_normal(np.zeros(d), cov_m, n)  # :220
+                    rr = np.random.uniform(0, 1, n)                           # :235
+                    out = engine.mh_step_host_rng(gamma_new, mhstep_ratio, noise[lo:lo + n_local], rr[lo:lo + n_local])
+                else:
+                    out = engine.mh_step_device_rng(gamma_new, mhstep_ratio, mvn_transform(cov_m), seed_device,
+                                                    (step << 16) | j, lo)
+                tot = comm.allreduce_sum_i64([out["accepted_ever"], out["accepted_now"], out["n_failed"]])
             account(out)
             stats["rk_attempts_mh"] += out["rk_attempts"]
             stats["mutation_sweeps"] += 1
             stats["particle_mutation_steps"] += n
-            tot = comm.allreduce_sum_i64([out["accepted_ever"], out["accepted_now"], out["n_failed"]])
             acc_ever = int(tot[0])
             mh_log.append({"cov_m": cov_m, "mhstep_ratio": mhstep_ratio, "accepted_now": int(tot[1]),
                            "accepted_ever": acc_ever})

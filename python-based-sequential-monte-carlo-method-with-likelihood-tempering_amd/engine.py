@@ -242,6 +242,50 @@ class HipEngine:
         self._ck(self.L.smc_ess_partials(self.ctx, float(max_lk), _dp(gms), k, _dp(sw), _dp(sw2)), "smc_ess_partials")
         return sw, sw2
 
+    # ---- the same stages reduced over all ranks on the device (RCCL in place, one read-back) ------
+    def max_lk_global(self):
+        v = ctypes.c_double(0)
+        self._ck(self.L.smc_max_lk_global(self.ctx, ctypes.byref(v)), "smc_max_lk_global")
+        return v.value
+
+    def ess_partials_global(self, max_lk, gms):
+        gms = _f64(gms)
+        k = gms.shape[0]
+        sw, sw2 = np.empty(k), np.empty(k)
+        self._ck(self.L.smc_ess_partials_global(self.ctx, float(max_lk), _dp(gms), k, _dp(sw), _dp(sw2)),
+                 "smc_ess_partials_global")
+        return sw, sw2
+
+    def resample_global(self, max_lk, gm, sum_w, wrand, first_step):
+        o, cs = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._ck(self.L.smc_resample_global(self.ctx, float(max_lk), float(gm), float(sum_w), float(wrand),
+                                            int(bool(first_step)), ctypes.byref(o), ctypes.byref(cs)), "smc_resample_global")
+        return {"n_offspring": o.value, "count_sum": cs.value}
+
+    def mh_iteration_device_rng(self, gamma, mhstep_ratio, w_cov, seed, stream, global_offset=0):
+        """One fused Metropolis iteration (moments -> cov_m -> factor -> propose -> solve -> accept -> counts), all ranks
+        together.  Accept counts and n_failed are totals over all ranks."""
+        w_cov = _f64(w_cov, (self.dim, self.dim))
+        o = self._mh_out()
+        cov = np.empty((self.dim, self.dim))
+        self._ck(self.L.smc_mh_iteration_device_rng(self.ctx, float(gamma), float(mhstep_ratio), _dp(w_cov), int(seed),
+                                                    int(stream), int(global_offset), *[ctypes.byref(x) for x in o], _dp(cov)),
+                 "smc_mh_iteration_device_rng")
+        return {"accepted_now": o[0].value, "accepted_ever": o[1].value, "n_failed": o[2].value,
+                "rk_attempts": o[3].value, "cov_m": cov}
+
+    def proposal_factor_device(self, w_cov):
+        """cov_m = np.cov(p_filt.T, bias=True) * w_cov over all ranks and its multivariate_normal factor, both on the device."""
+        w_cov = _f64(w_cov, (self.dim, self.dim))
+        cov, xf = np.empty((self.dim, self.dim)), np.empty((self.dim, self.dim))
+        self._ck(self.L.smc_proposal_factor_device(self.ctx, _dp(w_cov), _dp(cov), _dp(xf)), "smc_proposal_factor_device")
+        return cov, xf
+
+    def mh_iteration_last_transform(self):
+        out = np.empty((self.dim, self.dim))
+        self._ck(self.L.smc_mh_iteration_last_transform(self.ctx, _dp(out)), "smc_mh_iteration_last_transform")
+        return out
+
     # ---- resampling ----------------------------------------------------------------------------
     def resample_phase1(self, max_lk, gm, sum_w):
         r, c = ctypes.c_double(0), ctypes.c_int64(0)

@@ -144,3 +144,54 @@ class OracleEngine:
         self.r_ac = np.maximum(self.r_ac, r.astype(np.uint8))
         return {"accepted_now": int(r.sum()), "accepted_ever": int(self.r_ac.sum()), "n_failed": info["n_failed"],
                 "rk_attempts": info["n_attempts"]}
+
+    # the *_global entry points (include/smc_hip.h): the engine reduces over the ranks itself - here through
+    # torch.distributed, in the product through RCCL on the device buffers
+    def _comm(self):
+        from _torch_comm import TorchDistComm
+        if self.world == 1:
+            return None
+        if getattr(self, "_tc", None) is None:
+            self._tc = TorchDistComm()
+        return self._tc
+
+    def max_lk_global(self):
+        c = self._comm()
+        v = self.max_lk_local()
+        return float(c.allreduce_max([v])[0]) if c else v
+
+    def ess_partials_global(self, max_lk, gms):
+        sw, sw2 = self.ess_partials(max_lk, gms)
+        c = self._comm()
+        if c:
+            tot = c.allreduce_sum(np.concatenate([sw, sw2]))
+            sw, sw2 = tot[:len(gms)], tot[len(gms):]
+        return sw, sw2
+
+    def resample_global(self, max_lk, gm, sum_w, wrand, first_step):
+        c = self._comm()
+        r_loc, c_loc = self.resample_phase1(max_lk, gm, sum_w)
+        r_all = c.allgather([r_loc])[:, 0] if c else np.array([r_loc])
+        c_all = c.allgather_i64([c_loc])[:, 0] if c else np.array([c_loc])
+        prefix = 0.0
+        for q in range(self.rank):
+            prefix = prefix + float(r_all[q])
+        o_loc = self.resample_phase2(max_lk, gm, sum_w, prefix, wrand)
+        o_all = c.allgather_i64([o_loc])[:, 0] if c else np.array([o_loc])
+        bases = np.concatenate([[0], np.cumsum(o_all)[:-1]]).astype(np.int64)
+        self.resample_phase3(bases, o_all, first_step)
+        return {"n_offspring": int(o_all.sum()), "count_sum": int(c_all.sum())}
+
+
+class EngineSideComm:
+    """What comm.RcclComm is to the HipEngine: `on_device` tells the driver to use the engine's *_global entry points;
+    the remaining host-side collectives (parity mode draws the noise on the host, so its moments still go through the
+    communicator) are delegated."""
+    on_device = True
+
+    def __init__(self, inner):
+        self._c = inner
+        self.rank, self.size = inner.rank, inner.size
+
+    def __getattr__(self, name):
+        return getattr(self._c, name)

@@ -28,3 +28,43 @@ def test_bench_prints_one_json_line_with_the_contract_fields(extra):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
+# ---- N > 1 launch plumbing, no GPU needed -------------------------------------------------------------------------------
+def _run(cmd, env=None, timeout=240):
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` - the way the driver calls the 1-GPU bench - must start the N rank processes itself (the
+    parent makes no GPU call), hand RCCL's 128-byte id from rank 0 to the others, and relay rank 0's single JSON line."""
+    p = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"launch_check": True, "world": 2, "ranks_seen": [0, 1], "same_id": True}
+
+
+def test_bench_launcher_propagates_a_failed_rank():
+    env = dict(os.environ, SMC_BENCH_FAIL_RANK="1")
+    p = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], env=env)
+    assert p.returncode == 3 and "the run is void" in p.stderr
+
+
+def test_bench_under_torch_distributed_run():
+    """The contract's launcher for N > 1: ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+              "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["same_id"] is True
+
+
+def test_bench_does_not_import_torch():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in src

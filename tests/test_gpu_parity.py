@@ -721,6 +721,114 @@ def test_rccl_call_sequence_single_rank(pkg, data, golden_run, monkeypatch):
     assert np.abs(out["p_pred"] - g["final_p_pred"]).max() < 1e-9
 
 
+def _row_signs(a):
+    """Rows with their largest component positive (the sign convention of mh_transform_kernel; LAPACK's is arbitrary)."""
+    a = np.array(a, dtype=float)
+    for i in range(len(a)):
+        if a[i, np.argmax(np.abs(a[i]))] < 0:
+            a[i] = -a[i]
+    return a
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_fused_mh_iteration_equals_its_parts(pkg, data, force_rccl, monkeypatch):
+    """smc_mh_iteration_device_rng (Micmem_SMC_main.py:212-241 in one call: device-side moments -> cov_m -> the
+    multivariate_normal factor on the device -> propose -> solve -> accept -> counts) against the same iteration composed
+    from its parts on the host.  Pins:
+      * cov_m equals np.cov(p_filt.T, bias=True) * w_cov to summation-order tolerance;
+      * the device factor equals driver.mvn_transform(cov_m) - NumPy's sqrt(s)[:, None] * v of svd(cov_m) - row for row up
+        to the sign of a row (1e-10 relative), and factor^T factor == cov_m;
+      * fed with that very factor, smc_mh_step_device_rng makes bit-identical decisions and particles (same Philox keys).
+    With SMC_FORCE_RCCL=1 the three in-place ncclAllReduce calls of the fused path run on a one-rank communicator."""
+    if force_rccl:
+        monkeypatch.setenv("SMC_FORCE_RCCL", "1")
+    n = 20000
+    s = pkg.SMCSettings(n_particle=n)
+    th = mixed_particles(n, seed=9)
+    th[: n // 2] = np.array([1.2, 0.5, 0.03]) + np.random.RandomState(2).standard_normal((n // 2, 3)) * [0.2, 0.1, 0.004]
+    w_cov = s.w_cov()
+    outs = []
+    for fused in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            comm = pkg.RcclComm(eng, 0, 1, lambda uid: uid) if force_rccl else pkg.SingleComm()
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            eng.loglik(pkg.SMC_SET_PRED)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+            if fused:
+                out = eng.mh_iteration_device_rng(0.3, 0.7, w_cov, 99, (5 << 16) | 2, 0)
+                xf = eng.mh_iteration_last_transform()
+            else:
+                cov_host = pkg.proposal_cov(eng, comm, s, w_cov)
+                out = eng.mh_step_device_rng(0.3, 0.7, outs[0]["xf"], 99, (5 << 16) | 2, 0)
+                out["cov_m"] = cov_host
+                xf = outs[0]["xf"]
+            outs.append({"out": out, "xf": xf, "filt": eng.download_particles(pkg.SMC_SET_FILT),
+                         "lk": eng.download_lk(pkg.SMC_SET_FILT), "flags": eng.download_accept_flags()})
+    a, b = outs
+    cov_np = np.cov(th.T, bias=True) * w_cov
+    assert np.abs(a["out"]["cov_m"] - cov_np).max() <= 1e-11 * np.abs(cov_np).max()
+    assert np.abs(a["out"]["cov_m"] - b["out"]["cov_m"]).max() <= 1e-13 * np.abs(cov_np).max()
+    ref = pkg.mvn_transform(a["out"]["cov_m"])                      # NumPy / LAPACK on the host
+    assert np.abs(a["xf"].T @ a["xf"] - a["out"]["cov_m"]).max() <= 1e-13 * np.abs(cov_np).max()
+    assert np.abs(_row_signs(a["xf"]) - _row_signs(ref)).max() <= 1e-10 * np.abs(ref).max()
+    assert np.array_equal(_row_signs(a["xf"]), a["xf"])           # the kernel's own sign convention
+    for k in ("accepted_now", "accepted_ever", "n_failed", "rk_attempts"):
+        assert a["out"][k] == b["out"][k], k
+    assert 0 < a["out"]["accepted_now"] < n
+    assert np.array_equal(a["filt"], b["filt"]) and np.array_equal(a["lk"], b["lk"]) and np.array_equal(a["flags"], b["flags"])
+
+
+@pytest.mark.parametrize("d", [2, 5, 8])
+def test_device_mvn_factor_any_dimension(pkg, d):
+    """smc_proposal_factor_device for d != 3 (the methanation model has d = 5; SMC_MAX_DIM = 8) on a badly scaled, correlated
+    cloud: cov_m against NumPy, the Jacobi factor against NumPy's SVD factor row for row (up to the sign of a row)."""
+    n = 4096
+    rs = np.random.RandomState(d)
+    scale = 10.0 ** rs.uniform(-3, 2, d)
+    mix = rs.standard_normal((d, d))
+    x = rs.standard_normal((n, d)) @ mix * scale
+    w = np.full((d, d), 0.5)
+    with pkg.HipEngine(n, d, device=0) as eng:
+        eng.upload_particles(pkg.SMC_SET_FILT, x)
+        cov, xf = eng.proposal_factor_device(w)
+    ref_cov = np.cov(x.T, bias=True) * w
+    assert np.abs(cov - ref_cov).max() <= 1e-11 * np.abs(ref_cov).max()
+    ref = pkg.mvn_transform(cov)
+    assert np.abs(xf.T @ xf - cov).max() <= 1e-12 * np.abs(cov).max()
+    assert np.abs(_row_signs(xf) - _row_signs(ref)).max() <= 1e-9 * np.abs(ref).max()
+
+
+def test_global_reductions_on_a_one_rank_communicator(pkg, data, monkeypatch):
+    """The *_global entry points (partial on the device -> ncclAllReduce / ncclAllGather in place -> one read-back) on a
+    one-rank RCCL communicator must return exactly what the *_local ones do, and a complete run through them
+    (run_smc with RcclComm: on-device reductions, smc_resample_global, fused Metropolis iterations) must equal the run with
+    no communicator at all, bit for bit."""
+    n = 30000
+    th = mixed_particles(n, seed=12)
+    runs = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("SMC_FORCE_RCCL", "1")
+        with make_engine(pkg, data, n) as eng:
+            comm = pkg.RcclComm(eng, 0, 1, lambda uid: uid) if force else pkg.SingleComm()
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            eng.loglik(pkg.SMC_SET_PRED)
+            m_loc, m_glob = eng.max_lk_local(), eng.max_lk_global()
+            gms = [1.0, 0.5, 0.1, 0.01, 1e-3]
+            sw_l, sw2_l = eng.ess_partials(m_loc, gms)
+            sw_g, sw2_g = eng.ess_partials_global(m_glob, gms)
+            assert m_loc == m_glob and np.array_equal(sw_l, sw_g) and np.array_equal(sw2_l, sw2_g)
+            out = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n), comm=comm, rng="device", verbose=False, seed_device=3)
+            runs.append(out)
+    a, b = runs
+    assert a["gamma"] == b["gamma"] == 1.0
+    assert [r["gamma_new"] for r in a["records"]] == [r["gamma_new"] for r in b["records"]]
+    assert [r["n_accept"] for r in a["records"]] == [r["n_accept"] for r in b["records"]]
+    assert all(r["n_offspring"] == n for r in b["records"])
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+
+
 # ---------------------------------------------------------------------------------------------------
 # multi-rank path with the real kernels on one GPU (loopback exchange instead of RCCL send/recv)
 # ---------------------------------------------------------------------------------------------------

@@ -1,5 +1,6 @@
-"""N > 1 path on CPU: world_size-2 gloo runs of the PRODUCT driver (run_smc + TorchDistComm) over a
-CPU test-double engine, compared with the single-process oracle run on the same seed.  Validates the
+"""N > 1 path on CPU: world_size-2 gloo runs of the PRODUCT driver (run_smc) over a CPU test-double engine with a gloo
+communicator (tests/_torch_comm.py) - once with the reductions composed by the driver (host-side communicator) and once
+through the engine's *_global entry points (the shape of the product's RCCL path) - compared with the single-process oracle run on the same seed.  Validates the
 sharded control logic: global max / sums, residual prefix across ranks, output-slot bases, particle
 exchange plan, MH loop control, identical random streams on every rank."""
 import os
@@ -20,14 +21,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, seed, q):
+def _worker(rank, world, port, n, seed, q, engine_side):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     import __graft_entry__ as g
-    from _cpu_engine import OracleEngine
+    from _cpu_engine import EngineSideComm, OracleEngine
+    from _torch_comm import TorchDistComm
     pkg = g.load_package()
     O = g.load_oracle()
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,7 +37,7 @@ def _worker(rank, world, port, n, seed, q):
         data = O.MMData.load()
         s = pkg.SMCSettings(n_particle=n, seed=seed)
         eng = OracleEngine(O, data, s.priors, n // world, n, rank, world, dist)
-        comm = pkg.TorchDistComm()
+        comm = EngineSideComm(TorchDistComm()) if engine_side else TorchDistComm()
         out = pkg.run_smc(eng, s, comm=comm, rng="numpy", verbose=False)
         q.put((rank, out["p_pred"], out["lk"], [r["gamma_new"] for r in out["records"]],
                [r["n_accept"] for r in out["records"]], [r["last_j"] for r in out["records"]], out["logZ"],
@@ -44,13 +46,13 @@ def _worker(rank, world, port, n, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,seed", [(128, 20250205), (200, 3)])
-def test_two_rank_gloo_run_equals_single_process_oracle(O, data, n, seed):
+@pytest.mark.parametrize("n,seed,engine_side", [(128, 20250205, False), (200, 3, False), (128, 20250205, True)])
+def test_two_rank_gloo_run_equals_single_process_oracle(O, data, n, seed, engine_side):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, seed, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, seed, q, engine_side)) for r in range(2)]
     for p in procs:
         p.start()
     try:
