@@ -10,7 +10,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmc_hip.so")
+# SMC_HIP_LIB: another build of the same library (A/B timing of kernel variants on one box, tools/); default: the in-tree one
+LIB_PATH = os.environ.get("SMC_HIP_LIB") or os.path.join(_HERE, "libsmc_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "smc_hip.h")
 
 SMC_SET_PRED, SMC_SET_FILT = 0, 1

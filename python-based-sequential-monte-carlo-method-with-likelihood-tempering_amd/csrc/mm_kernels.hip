@@ -39,6 +39,11 @@ namespace smc {
 __global__ void __launch_bounds__(256)
 mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int64_t stride, int64_t n,
                   double *__restrict__ prop, int64_t pstride, uint8_t *__restrict__ p0_out) {
+    if (blockIdx.x == 0) {   // fused iteration: the counters of this sweep and the work queue of its solve start from zero
+        if (mh.zero_counters && threadIdx.x < sizeof(SweepCounters) / 8)
+            reinterpret_cast<unsigned long long *>(mh.zero_counters)[threadIdx.x] = 0ull;
+        if (mh.zero_queue && threadIdx.x == 64) mh.zero_queue[0] = 0ull;
+    }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const double f0 = filt[p], f1 = filt[stride + p], f2 = filt[2 * stride + p];
@@ -224,7 +229,17 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                  uint8_t *__restrict__ r_ac, SweepCounters *__restrict__ counters, double *__restrict__ dbg_lk2,
                  uint8_t *__restrict__ dbg_r) {
     __shared__ unsigned long long s_cnt[4][4];
+    __shared__ double s_mom[4][9];
     unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0;
+    // moments of the SELECTED particles about mh.moment_shift (MODE 1, fused iteration): sum y, sum y y^T (upper), y = x - shift
+    double m0 = 0, m1 = 0, m2 = 0, c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
+    const bool acc_mom = (MODE == 1) && mh.moment_rows != nullptr;
+    double sh0 = 0, sh1 = 0, sh2 = 0;
+    if (acc_mom) {
+        sh0 = mh.moment_shift[0];
+        sh1 = mh.moment_shift[1];
+        sh2 = mh.moment_shift[2];
+    }
     // grid-stride: a few hundred blocks, so that the counters cost one atomic per block, not per wave
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const int n_ex = mm.n_ex;
@@ -268,9 +283,16 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
             if (mh.prior_mode != SMC_PRIOR_MODE_RATIO) pp = pp * p0;
             const double r = (pp >= rr) ? 1.0 : 0.0;
             const double nr = 1.0 - r;
+            double sel[3];
             for (int c = 0; c < 3; ++c) {
                 const double th = theta[c * stride + p], f = filt[c * fstride + p];
-                filt[c * fstride + p] = __dadd_rn(__dmul_rn(th, r), __dmul_rn(f, nr));
+                sel[c] = __dadd_rn(__dmul_rn(th, r), __dmul_rn(f, nr));
+                filt[c * fstride + p] = sel[c];
+            }
+            if (acc_mom) {
+                const double y0 = sel[0] - sh0, y1 = sel[1] - sh1, y2 = sel[2] - sh2;
+                m0 += y0; m1 += y1; m2 += y2;
+                c00 += y0 * y0; c01 += y0 * y1; c02 += y0 * y2; c11 += y1 * y1; c12 += y1 * y2; c22 += y2 * y2;
             }
             lk_io[p] = __dadd_rn(__dmul_rn(lk2, r), __dmul_rn(lk1, nr));
             const uint8_t ever = (uint8_t)(r_ac[p] | (uint8_t)(r != 0.0));
@@ -297,7 +319,19 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
         s_cnt[w][2] = acc_now;
         s_cnt[w][3] = acc_ever;
     }
+    if (acc_mom) {   // fixed-order block sums -> one row of 9 per block (deterministic; reduced by moments_reduce_kernel)
+        double mv[9] = {m0, m1, m2, c00, c01, c02, c11, c12, c22};
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            double v = mv[q];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if ((threadIdx.x & 63) == 0) s_mom[w][q] = v;
+        }
+    }
     __syncthreads();
+    if (acc_mom && threadIdx.x < 9)
+        mh.moment_rows[(size_t)blockIdx.x * 9 + threadIdx.x] =
+            ((s_mom[0][threadIdx.x] + s_mom[1][threadIdx.x]) + s_mom[2][threadIdx.x]) + s_mom[3][threadIdx.x];
     if (threadIdx.x < 4) {
         const unsigned long long v = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] +
                                      s_cnt[3][threadIdx.x];
@@ -316,7 +350,8 @@ static unsigned finish_grid(int64_t n) {
     return (unsigned)(g < 1024 ? (g < 1 ? 1 : g) : 1024);
 }
 
-static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred) {
+static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
+                         bool queue_cleared = false) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
     a.theta = theta;
@@ -327,7 +362,7 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.info = ctx->d_info;
     a.pred = pred;
     a.queue = ctx->d_queue;
-    (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
+    if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = (size_t)(2 * mm.n_ex * mm.n_t + mm.n_ex) * sizeof(double);
     // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more blocks than chunks
     const int64_t chunks = (((n + kWave - 1) / kWave) * kWave * mm.n_ex + kChunk - 1) / kChunk;
@@ -358,7 +393,8 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
     const bool dbg = ctx->debug_capture != 0;
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
-    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr);
+    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.zero_queue != nullptr);
+    ctx->moment_rows_n = mh.moment_rows ? (int)finish_grid(n) : 0;
     hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        P.theta, P.stride, n, ctx->d_sum_r2, ctx->d_info, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac,
                        ctx->d_counters, dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);

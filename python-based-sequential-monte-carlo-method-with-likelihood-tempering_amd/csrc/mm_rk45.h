@@ -56,13 +56,23 @@ namespace smc {
 #define RK_MAX_ATTEMPTS (1 << 20)  // hard bound so that every wave drains; SciPy has none
 
 // a / b with a shorter dependent chain than the compiler's IEEE sequence (v_div_scale, v_rcp, two
-// Newton steps, v_div_fmas, v_div_fixup: ~30 ns on the chain vs 18 ns here).  v_rcp_f64 is accurate to
-// 2^-24.4 (measured, tools/div_probe.hip), so ONE Newton step gives 2^-48.8 and the Markstein
-// correction q + (a - b*q)*r rounds correctly: bit-identical to a/b on 4M random operands.  It has no
-// scaling and no special-case fix-up, so it is only used inside rk_attempt_core<true>, whose caller
+// Newton steps, v_div_fmas, v_div_fixup: ~30 ns on the chain).  v_rcp_f64 is accurate to 2^-24.4
+// (measured, tools/div_probe.hip), so ONE Newton step gives 2^-48.8 and the Markstein correction
+// q + (a - b*q)*r rounds correctly (the error of the sum before rounding is ~2^-97 relative):
+// bit-identical to a/b on 4M wide-exponent operand pairs and 4M right-hand-side-shaped ones, both forms:
+//   lean_div6  rcp -> e -> r -> q = a*r -> rem -> result: six dependent operations, six instructions.  The product path.
+//   lean_div5  the Newton step applied to the QUOTIENT, q1 = q0 + q0*e with q0 = a*r0, beside the one on the reciprocal:
+//              rcp -> e -> q1 -> rem -> result, five dependent operations but seven instructions.  Tried this round to
+//              shorten the serial chain of a stiff solve, and NOT adopted: alone on the GPU a 12 562-attempt solve takes
+//              0.419 us per attempt with lean_div6 and 0.460 us with lean_div5 (+9.9 %; tools/attempt_probe.hip, both
+//              variants alternating in one process, profiles/r02_attempt_probe.log), and the bulk loop is 2 % slower too
+//              (profiles/r02_ab_lean_div.log).  The attempt is not a pure latency chain: ~200 vector instructions at >= 4
+//              issue cycles each are ~2/3 of its ~1000 cycles, so an extra instruction per division costs more than the
+//              dependent operation it removes.  Kept as a template option for the probe only.
+// No scaling and no special-case fix-up, so they are only used inside rk_attempt_core<DIV != 0>, whose caller
 // re-runs the whole attempt with IEEE division whenever the result is not finite; quotients in the
 // denormal range may differ from IEEE in the last bits (they sit > 280 orders below atol).
-__device__ __forceinline__ double lean_div(double a, double b) {
+__device__ __forceinline__ double lean_div6(double a, double b) {
     double r = __builtin_amdgcn_rcp(b);
     const double e = fma(-b, r, 1.0);
     r = fma(r, e, r);
@@ -70,15 +80,25 @@ __device__ __forceinline__ double lean_div(double a, double b) {
     const double rem = fma(-b, q, a);
     return fma(rem, r, q);
 }
-template <bool LEAN>
+__device__ __forceinline__ double lean_div5(double a, double b) {
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e = fma(-b, r0, 1.0);
+    const double q0 = a * r0;            // beside e
+    const double r = fma(r0, e, r0);     // beside q1
+    const double q1 = fma(q0, e, q0);
+    const double rem = fma(-b, q1, a);
+    return fma(rem, r, q1);
+}
+constexpr int kDivIeee = 0, kDivLean6 = 1, kDivLean5 = 2;
+template <int DIV>
 __device__ __forceinline__ double mm_div(double a, double b) {
-    return LEAN ? lean_div(a, b) : a / b;
+    return DIV == kDivLean6 ? lean_div6(a, b) : DIV == kDivLean5 ? lean_div5(a, b) : a / b;
 }
-template <bool LEAN>
+template <int DIV>
 __device__ __forceinline__ double mm_rhs_t(double S, double negVmax, double Km) {
-    return mm_div<LEAN>(negVmax * S, Km + S);  // ((-Vmax)*S)/(Km+S), Micmem_likelihood.py:15
+    return mm_div<DIV>(negVmax * S, Km + S);  // ((-Vmax)*S)/(Km+S), Micmem_likelihood.py:15
 }
-__device__ __forceinline__ double mm_rhs(double S, double negVmax, double Km) { return mm_rhs_t<false>(S, negVmax, Km); }
+__device__ __forceinline__ double mm_rhs(double S, double negVmax, double Km) { return mm_rhs_t<kDivIeee>(S, negVmax, Km); }
 
 // Python's min(a,b)/max(a,b): keep a unless b is strictly better (NaN never is)
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
@@ -195,7 +215,7 @@ __device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km
 struct RkStages {
     double k1, k2, k3, k4, k5, k6, y_new, error_norm;
 };
-template <bool LEAN>
+template <int LEAN /* kDiv* */>
 __device__ __forceinline__ RkStages rk_attempt_core(double y, double k0, double h, double negVmax, double Km,
                                                     double rtol, double atol) {
     RkStages s;
@@ -215,7 +235,7 @@ __device__ __forceinline__ RkStages rk_attempt_core(double y, double k0, double 
 
 // One step attempt.  Returns 0 while the item is still running, 1 when it finished (t reached
 // t_bound), 2 when it failed (step size underflow, rk.py:133-134; SciPy status -1).
-template <bool WRITE_PRED>
+template <bool WRITE_PRED, int DIV = kDivLean6>
 __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, const double *s_P, int n_t, double rtol,
                                                double atol, double *pred) {
     // rk.py:133-134 TOO_SMALL_STEP (plus the hard attempt bound): tested together with the other rare
@@ -228,7 +248,7 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, co
     it.h_abs = fabs(h);
 
     const double k0 = it.f;
-    RkStages st = rk_attempt_core<true>(y, k0, h, negVmax, Km, rtol, atol);
+    RkStages st = rk_attempt_core<DIV>(y, k0, h, negVmax, Km, rtol, atol);
     ++it.attempts;
 
     // 0.9 * error_norm ** -0.2 is needed by both branches of rk.py:149-171 (error_norm == 0 gives inf,
@@ -243,7 +263,7 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, co
     if (fail || redo || (accept && it.t_next <= t_new)) {
         if (fail) return 2;
         if (redo) {
-            st = rk_attempt_core<false>(y, k0, h, negVmax, Km, rtol, atol);
+            st = rk_attempt_core<kDivIeee>(y, k0, h, negVmax, Km, rtol, atol);
             pw = 0.9 * pow_minus_fifth(st.error_norm);
             accept = st.error_norm < 1.0;
         }

@@ -390,6 +390,7 @@ static int check_set(smc_ctx *c, int set, int64_t n) {
 int smc_upload_particles(smc_ctx *c, int set, const double *aos, int64_t n) {
     if (check_set(c, set, n)) return 1;
     HIPC(c, hipSetDevice(c->device));
+    c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
     HIPC(c, hipMemcpyAsync(c->d_stage, aos, (size_t)n * c->dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
     launch_aos_to_soa(c, c->d_stage, c->set[set].theta, n, c->dim, c->set[set].stride);
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -790,6 +791,7 @@ int smc_debug_rccl_self_exchange(smc_ctx *c, int64_t row, int64_t cnt, int64_t d
     if (!c) return fail(nullptr, "NULL context");
     if (row < 0 || cnt < 1 || row + cnt > c->n_local || dst_row < 0 || dst_row + cnt > c->n_local) return fail(c, "bad row range");
     HIPC(c, hipSetDevice(c->device));
+    c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
     const int d = c->dim;
     ParticleSet &P = c->set[SMC_SET_PRED];
     if (cnt > c->sendbuf_cap) {
@@ -817,6 +819,7 @@ int smc_debug_rccl_self_exchange(smc_ctx *c, int64_t row, int64_t cnt, int64_t d
 int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *offspring_all, int first_step) {
     if (!c) return fail(nullptr, "NULL context");
     HIPC(c, hipSetDevice(c->device));
+    c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
     const int W = c->world, R = c->rank, d = c->dim;
     const int64_t nl = c->n_local;
     ParticleSet &F = c->set[SMC_SET_FILT];
@@ -912,6 +915,7 @@ int smc_resample_phase3_pull(smc_ctx *c) {
     if (!c) return fail(nullptr, "NULL context");
     if (c->peers.empty()) return fail(c, "smc_debug_set_local_peers has not been called");
     HIPC(c, hipSetDevice(c->device));
+    c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
     const int W = c->world, R = c->rank, d = c->dim;
     const int64_t nl = c->n_local;
     ParticleSet &F = c->set[SMC_SET_FILT];
@@ -984,6 +988,7 @@ int smc_mh_step_host_rng(smc_ctx *c, double gamma, double mhstep_ratio, const do
     if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
     if (n != c->n_local) return fail(c, "smc_mh_step_host_rng: n must equal the context's n_local");
     HIPC(c, hipSetDevice(c->device));
+    c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
     const int d = c->dim;
     HIPC(c, hipMemcpyAsync(c->d_stage, noise, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
     launch_aos_to_soa(c, c->d_stage, c->d_noise, n, d, n);
@@ -1010,6 +1015,7 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
     if (!c) return fail(nullptr, "NULL context");
     if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
     HIPC(c, hipSetDevice(c->device));
+    c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
     if (counters_begin(c)) return 1;
     MHParams mh{};
     mh.gamma = gamma;
@@ -1028,11 +1034,34 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
     return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
 }
 
+// d_small layout of the fused iteration (doubles): what one read-back of kFusedWords words brings to the host
+constexpr int kV = 0;        // [sum y (d) | sum y y^T (d(d+1)/2) | accepted_now, accepted_ever, n_failed]: ONE all-reduce
+constexpr int kSums = 64;    // two-pass start of a step: column sums, then
+constexpr int kCent = 72;    //   sums centred about the global mean
+constexpr int kShift = 112;  // shift vector of the carried moments = mean of the previous iteration
+constexpr int kCov = 128;    // cov_m
+constexpr int kXf = 192;     // its multivariate_normal factor
+constexpr int kFusedWords = 256;
+
+static int two_pass_factor(smc_ctx *c, const double *w_cov) {
+    const int d = c->dim, npair = d * (d + 1) / 2;
+    double *S = c->d_small;
+    ScopedTimer tm(c, SMC_T_MOMENTS);
+    launch_moment_sums(c, S + kSums);
+    if (dev_allreduce(c, S + kSums, (size_t)d, ncclDouble, ncclSum)) return 1;
+    launch_moment_centered_dev(c, S + kSums, S + kCent);
+    if (dev_allreduce(c, S + kCent, (size_t)npair, ncclDouble, ncclSum)) return 1;
+    launch_mh_transform(c, S + kCent, S + kSums, w_cov, S + kShift, S + kCov, S + kXf);
+    return 0;
+}
+
 // One Metropolis iteration of the device-RNG mode with everything on the stream (Micmem_SMC_main.py:212-241):
-//   column sums -> [allreduce] -> centred sums about the global mean -> [allreduce] -> cov_m = cov * w_cov and its
-//   multivariate_normal factor (one thread) -> propose -> solve -> accept/select -> counters -> [allreduce] -> ONE read-back.
-// d_small layout: [0, d) sums | [16, 16 + d(d+1)/2) centred sums | [64, 64 + d*d) cov_m | [128, 128 + d*d) factor |
-// [256, 260) counters summed over the ranks.
+//   first iteration after the FILT set changed: column sums -> [allreduce] -> sums centred about the global mean ->
+//   [allreduce] -> cov_m = cov * w_cov and its multivariate_normal factor (one thread);
+//   then propose -> solve -> accept/select -> [ONE allreduce of moments + accept counts] -> ONE read-back.
+// Michaelis-Menten path: the accept kernel accumulates the moments of the particles it selects (about the previous mean),
+// so the following iterations start at the factor kernel - no pass over the particles, no further all-reduce (SURVEY.md
+// 8(e), rows A6/A10: "fused with the accept count").
 int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed,
                                 uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
                                 int64_t *n_failed, int64_t *rk_attempts_local, double *cov_m) {
@@ -1040,18 +1069,16 @@ int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, c
     if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
     if (!w_cov) return fail(c, "smc_mh_iteration_device_rng: w_cov is NULL");
     HIPC(c, hipSetDevice(c->device));
-    const int d = c->dim, npair = d * (d + 1) / 2;
-    double *d_sums = c->d_small, *d_cent = c->d_small + 16, *d_cov = c->d_small + 64, *d_xf = c->d_small + 128;
-    unsigned long long *d_tot = (unsigned long long *)(c->d_small + 256);
-    {
+    const int d = c->dim;
+    const bool mm = c->model_kind == 1;
+    double *S = c->d_small;
+    if (mm && c->moments_valid) {
         ScopedTimer tm(c, SMC_T_MOMENTS);
-        launch_moment_sums(c, d_sums);
-        if (dev_allreduce(c, d_sums, (size_t)d, ncclDouble, ncclSum)) return 1;
-        launch_moment_centered_dev(c, d_sums, d_cent);
-        if (dev_allreduce(c, d_cent, (size_t)npair, ncclDouble, ncclSum)) return 1;
-        launch_mh_transform(c, d_cent, w_cov, d_cov, d_xf);
+        launch_mh_transform(c, S + kV, nullptr, w_cov, S + kShift, S + kCov, S + kXf);
+    } else if (two_pass_factor(c, w_cov)) {
+        return 1;
     }
-    if (counters_begin(c)) return 1;
+    c->moments_valid = false;
     MHParams mh{};
     mh.gamma = gamma;
     mh.ratio = mhstep_ratio;
@@ -1061,52 +1088,51 @@ int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, c
     mh.seed = seed;
     mh.stream = stream;
     mh.global_offset = global_offset;
-    mh.transform_dev = d_xf;
+    mh.transform_dev = S + kXf;
+    if (mm) {      // the propose kernel clears counters and queue, the accept kernel leaves the moment rows in d_partials
+        mh.zero_counters = c->d_counters;
+        mh.zero_queue = c->d_queue;
+        mh.moment_shift = S + kShift;
+        mh.moment_rows = c->d_partials;
+    } else if (counters_begin(c)) {
+        return 1;
+    }
     {
         ScopedTimer tm(c, SMC_T_MH);
         if (c->model_kind == 2) launch_meth_mh(c, c->n_local, mh); else if (c->model_kind == 3) launch_user_mh(c, c->n_local, mh); else launch_mm_mh(c, c->n_local, mh);
     }
     HIPC(c, hipGetLastError());
     if (c->launch_failed) { c->launch_failed = false; return 1; }
-    // n_failed, rk_attempts, accepted_now, accepted_ever are the first four words of SweepCounters
-    static_assert(offsetof(SweepCounters, accepted_ever) == 24, "SweepCounters layout");
-    HIPC(c, hipMemcpyAsync(d_tot, c->d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
-    if (dev_allreduce(c, d_tot, 4, ncclUint64, ncclSum)) return 1;
-    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small + 64, (size_t)(256 + 4 - 64) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (counters_end(c)) return 1;      // local counters + the one synchronisation of the iteration
-    unsigned long long tot[4];
-    memcpy(tot, c->h_small + (256 - 64), sizeof tot);
-    if (n_failed) *n_failed = (int64_t)tot[0];
-    if (accepted_now) *accepted_now = (int64_t)tot[2];
-    if (accepted_ever) *accepted_ever = (int64_t)tot[3];
+    const int nv = mm ? d + d * (d + 1) / 2 : 0;
+    launch_moments_reduce(c, mm ? c->moment_rows_n : 0, nv, S + kV);
+    if (dev_allreduce(c, S + kV, (size_t)nv + 3, ncclDouble, ncclSum)) return 1;
+    HIPC(c, hipMemcpyAsync(c->h_small, S, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (counters_end(c)) return 1;      // this rank's counters + the one synchronisation of the iteration
+    c->moments_valid = mm;
+    if (accepted_now) *accepted_now = (int64_t)c->h_small[kV + nv];
+    if (accepted_ever) *accepted_ever = (int64_t)c->h_small[kV + nv + 1];
+    if (n_failed) *n_failed = (int64_t)c->h_small[kV + nv + 2];
     if (rk_attempts_local) *rk_attempts_local = (int64_t)c->h_counters->rk_attempts;
     if (cov_m)
-        for (int i = 0; i < d * d; ++i) cov_m[i] = c->h_small[i];
+        for (int i = 0; i < d * d; ++i) cov_m[i] = c->h_small[kCov + i];
     return 0;
 }
 
 // Stage A6 + the factor of A7 alone, over all ranks: cov_m and its multivariate_normal factor from the FILT set (no model
-// needed) - the first half of smc_mh_iteration_device_rng with a read-back.
+// needed) - the two-pass start of smc_mh_iteration_device_rng with a read-back.
 int smc_proposal_factor_device(smc_ctx *c, const double *w_cov, double *cov_m, double *transform) {
     if (!c) return fail(nullptr, "NULL context");
     if (!w_cov) return fail(c, "smc_proposal_factor_device: w_cov is NULL");
     HIPC(c, hipSetDevice(c->device));
-    const int d = c->dim, npair = d * (d + 1) / 2;
-    double *d_sums = c->d_small, *d_cent = c->d_small + 16, *d_cov = c->d_small + 64, *d_xf = c->d_small + 128;
-    {
-        ScopedTimer tm(c, SMC_T_MOMENTS);
-        launch_moment_sums(c, d_sums);
-        if (dev_allreduce(c, d_sums, (size_t)d, ncclDouble, ncclSum)) return 1;
-        launch_moment_centered_dev(c, d_sums, d_cent);
-        if (dev_allreduce(c, d_cent, (size_t)npair, ncclDouble, ncclSum)) return 1;
-        launch_mh_transform(c, d_cent, w_cov, d_cov, d_xf);
-    }
+    const int d = c->dim;
+    c->moments_valid = false;
+    if (two_pass_factor(c, w_cov)) return 1;
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small + 64, (size_t)(128 + 64) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < d * d; ++i) {
-        if (cov_m) cov_m[i] = c->h_small[i];
-        if (transform) transform[i] = c->h_small[64 + i];
+        if (cov_m) cov_m[i] = c->h_small[kCov + i];
+        if (transform) transform[i] = c->h_small[kXf + i];
     }
     return 0;
 }
@@ -1114,7 +1140,7 @@ int smc_proposal_factor_device(smc_ctx *c, const double *w_cov, double *cov_m, d
 // the d x d factor the last smc_mh_iteration_device_rng drew its proposals with (row-major; debugging / tests)
 int smc_mh_iteration_last_transform(smc_ctx *c, double *transform) {
     if (!c) return fail(nullptr, "NULL context");
-    for (int i = 0; i < c->dim * c->dim; ++i) transform[i] = c->h_small[(128 - 64) + i];
+    for (int i = 0; i < c->dim * c->dim; ++i) transform[i] = c->h_small[kXf + i];
     return 0;
 }
 

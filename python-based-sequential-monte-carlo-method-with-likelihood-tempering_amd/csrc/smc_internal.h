@@ -50,12 +50,20 @@ struct ParticleSet {  // SoA view: theta[c][i] = theta_base[c*stride + i]
     int64_t stride;
 };
 
+struct SweepCounters;
 struct MHParams {    // passed by value to the fused MH kernel
     double gamma, ratio;
     const double *noise;  // host-RNG mode: SoA d x n (device); nullptr in device-RNG mode
     const double *rr;     // host-RNG mode: n uniforms (device)
     double transform[SMC_MAX_DIM * SMC_MAX_DIM];  // device-RNG mode: z @ transform
     const double *transform_dev;  // if set: the same d x d factor in device memory (fused iteration), read instead
+    // fused iteration, Michaelis-Menten path: the accept kernel also accumulates the moments the NEXT iteration's proposal
+    // covariance needs, about the shift vector at moment_shift (d doubles, device), into per-block rows of moment_rows
+    const double *moment_shift;
+    double *moment_rows;
+    // ... and the propose kernel clears the sweep counters and the work queue (saves two memset launches per iteration)
+    SweepCounters *zero_counters;
+    unsigned long long *zero_queue;
     uint64_t seed, stream;
     int64_t global_offset;
     int device_rng;
@@ -140,6 +148,10 @@ struct smc_ctx {
     // host batch sweeps (drop-in sim_particle)
     double *d_hb_theta = nullptr, *d_hb_lk = nullptr, *d_hb_pred = nullptr;
     int64_t hb_cap = 0, hb_pred_cap = 0;
+    // fused Metropolis iterations: d_small holds the moments of the FILT set that the last accept kernel accumulated (valid
+    // until anything else writes the FILT set)
+    bool moments_valid = false;
+    int moment_rows_n = 0;           // per-block partial rows the last accept kernel wrote to d_partials
 
     // comm
     void *nccl_comm = nullptr;
@@ -160,7 +172,7 @@ namespace smc {
 
 // kernel launchers implemented in mm_kernels.hip
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred);
-void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
+void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);   // mh.moment_rows set: returns the row count in ctx->moment_rows_n
 int query_solve_blocks_per_cu();
 // implemented in meth_smc.hip
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);

@@ -12,7 +12,9 @@ int ess_padded_k(int k);
 void launch_moment_sums(smc_ctx *c, double *d_out);
 void launch_moment_centered(smc_ctx *c, const double *mean, double *d_out);
 void launch_moment_centered_dev(smc_ctx *c, const double *d_sums, double *d_out);   // mean = d_sums / n_global on the device
-void launch_mh_transform(smc_ctx *c, const double *d_cent, const double *w_cov, double *d_cov, double *d_xform);
+void launch_mh_transform(smc_ctx *c, const double *d_mom, const double *d_sums, const double *w_cov, double *d_shift,
+                         double *d_cov, double *d_xform);
+void launch_moments_reduce(smc_ctx *c, int n_rows, int nv, double *d_out);
 void launch_resample_phase1(smc_ctx *c, double max_lk, double gm, double sum_w);
 void launch_resample_phase2(smc_ctx *c, double max_lk, double gm, double sum_w, double base, double wrand);
 void launch_offspring_from_scan(smc_ctx *c, int64_t *d_out);

@@ -246,16 +246,33 @@ __global__ void __launch_bounds__(kScanBlock) moment_centered_kernel(const doubl
 struct WCov {
     double w[SMC_MAX_DIM * SMC_MAX_DIM];
 };
-__global__ void mh_transform_kernel(const double *__restrict__ cent /* d(d+1)/2 centred sums, row-major upper */,
-                                    double n_global, WCov wcov, int d, double *__restrict__ cov_out,
+// Two sources of the second moments:
+//   sums != nullptr  two-pass (np.cov's own algorithm): `mom` = the d(d+1)/2 sums centred about the mean sums / N; the mean is
+//                    stored as the shift vector of the iterations that follow;
+//   sums == nullptr  carried: `mom` = [sum y (d) | sum y y^T (upper)] with y = x - shift, accumulated by the accept kernel of the
+//                    previous iteration about the mean of the iteration before (so |E y| << spread: no cancellation to speak
+//                    of): cov = E[y y^T] - E[y] E[y]^T, and the shift moves on to the new mean.
+__global__ void mh_transform_kernel(const double *__restrict__ mom, const double *__restrict__ sums, double n_global, WCov wcov,
+                                    int d, double *__restrict__ shift_io, double *__restrict__ cov_out,
                                     double *__restrict__ xform_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double A[SMC_MAX_DIM][SMC_MAX_DIM], V[SMC_MAX_DIM][SMC_MAX_DIM];
     const double inv_n = 1.0 / n_global;     // np.true_divide(1, fact), then c *= that (np.cov)
+    double ey[SMC_MAX_DIM];
+    for (int a = 0; a < d; ++a) {
+        if (sums) {
+            ey[a] = 0.0;
+            shift_io[a] = sums[a] / n_global;
+        } else {
+            ey[a] = mom[a] * inv_n;
+            shift_io[a] = shift_io[a] + ey[a];
+        }
+    }
+    const double *cent = sums ? mom : mom + d;
     int k = 0;
     for (int a = 0; a < d; ++a)
         for (int b = a; b < d; ++b) {
-            const double v = cent[k++] * inv_n;
+            const double v = cent[k++] * inv_n - ey[a] * ey[b];
             A[a][b] = v * wcov.w[a * d + b];
             A[b][a] = v * wcov.w[b * d + a];
         }
@@ -656,11 +673,34 @@ void launch_moment_centered_dev(smc_ctx *c, const double *d_sums, double *d_out)
                        c->dim, m, d_sums, (double)c->n_global, c->d_partials);
     hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
 }
-void launch_mh_transform(smc_ctx *c, const double *d_cent, const double *w_cov, double *d_cov, double *d_xform) {
+void launch_mh_transform(smc_ctx *c, const double *d_mom, const double *d_sums, const double *w_cov, double *d_shift,
+                         double *d_cov, double *d_xform) {
     WCov w{};
     for (int i = 0; i < c->dim * c->dim; ++i) w.w[i] = w_cov[i];
-    hipLaunchKernelGGL(mh_transform_kernel, dim3(1), dim3(64), 0, c->stream, d_cent, (double)c->n_global, w, c->dim, d_cov,
-                       d_xform);
+    hipLaunchKernelGGL(mh_transform_kernel, dim3(1), dim3(64), 0, c->stream, d_mom, d_sums, (double)c->n_global, w, c->dim,
+                       d_shift, d_cov, d_xform);
+}
+// per-block rows of nv doubles (accept kernel) -> out[0..nv), then the sweep's accept counters as doubles (exact below 2^53):
+// out[nv] = accepted_now, out[nv+1] = accepted_ever, out[nv+2] = n_failed - ONE vector for ONE all-reduce per iteration
+__global__ void __launch_bounds__(kScanBlock) moments_reduce_kernel(const double *__restrict__ rows, int n_rows, int nv,
+                                                                    const SweepCounters *__restrict__ counters,
+                                                                    double *__restrict__ out) {
+    __shared__ double lds[4];
+    for (int v = 0; v < nv; ++v) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n_rows; i += blockDim.x) s += rows[(size_t)i * nv + v];
+        s = block_sum(s, lds);
+        if (threadIdx.x == 0) out[v] = s;
+    }
+    if (threadIdx.x == 0) {
+        out[nv] = (double)counters->accepted_now;
+        out[nv + 1] = (double)counters->accepted_ever;
+        out[nv + 2] = (double)counters->n_failed;
+    }
+}
+void launch_moments_reduce(smc_ctx *c, int n_rows, int nv, double *d_out) {
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, n_rows, nv, c->d_counters,
+                       d_out);
 }
 
 static ResampleArgs make_args(smc_ctx *c, double max_lk, double gm, double sum_w, double wrand, double base) {

@@ -58,8 +58,8 @@ def sample_prior(priors, n_particle):
 
 samples = sample_prior(priors, n_particle)
 p_pred = np.zeros((n_particle, num_est_params))
-for _j, _name in enumerate(priors.keys()):
-    p_pred[:, _j] = samples[_name]
+for j, name in enumerate(priors.keys()):      # j, name (and i, df, data_i below) stay behind as module globals in the
+    p_pred[:, j] = samples[name]               # reference too, and `import *` hands them on: kept under the same names
 
 itr_max = _s.itr_max
 n_hist = 50
@@ -70,9 +70,10 @@ w_cov = _s.w_cov()
 dataset = []
 n_ex = 6
 base_path = "data/mm_pseudo_data"
-for _i in range(0, n_ex):
-    _df = pd.read_csv(f"{base_path}_{_i}.csv")
-    dataset.append({"t": _df["t"].values, "P_obs": _df["P_obs"].values, "S0": _df["S_true"].iloc[0]})
+for i in range(0, n_ex):
+    df = pd.read_csv(f"{base_path}_{i}.csv")
+    data_i = {"t": df["t"].values, "P_obs": df["P_obs"].values, "S0": df["S_true"].iloc[0]}
+    dataset.append(data_i)
 datapoint = len(dataset[0]["t"])
 obs_data = dataset
 

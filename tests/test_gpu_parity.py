@@ -779,6 +779,38 @@ def test_fused_mh_iteration_equals_its_parts(pkg, data, force_rccl, monkeypatch)
     assert np.array_equal(a["filt"], b["filt"]) and np.array_equal(a["lk"], b["lk"]) and np.array_equal(a["flags"], b["flags"])
 
 
+def test_fused_mh_iterations_carry_their_moments(pkg, data):
+    """From the second fused iteration of a step on, cov_m comes from moments the accept kernel of the previous iteration
+    accumulated over the particles it selected (about the previous mean) - no pass over the particles.  It must still be
+    np.cov(p_filt.T, bias=True) * w_cov of the population the iteration starts from, to summation-order tolerance, also
+    for a population whose spread (1e-3 in sigma) is far smaller than its location; and anything else that rewrites p_filt
+    (here: an upload) must send the next iteration back to the two-pass start."""
+    n = 50000
+    s = pkg.SMCSettings(n_particle=n)
+    w_cov = s.w_cov()
+    rs = np.random.RandomState(21)
+    th = np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((n, 3)) * np.array([0.025, 0.0295, 0.00094])
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        eng.loglik(pkg.SMC_SET_PRED)
+        eng.upload_particles(pkg.SMC_SET_FILT, th)
+        eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+        cur = th
+        for j in range(4):
+            out = eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 5, (9 << 16) | j, 0)
+            ref = np.cov(cur.T, bias=True) * w_cov
+            assert np.abs(out["cov_m"] - ref).max() <= 1e-11 * np.abs(ref).max(), j
+            new = eng.download_particles(pkg.SMC_SET_FILT)
+            moved = np.any(new != cur, axis=1).sum()
+            assert moved == out["accepted_now"] > 0.2 * n
+            cur = new
+        shifted = cur + np.array([0.5, -0.1, 0.001])
+        eng.upload_particles(pkg.SMC_SET_FILT, shifted)             # invalidates the carried moments
+        out = eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 5, (9 << 16) | 9, 0)
+        ref = np.cov(shifted.T, bias=True) * w_cov
+        assert np.abs(out["cov_m"] - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("d", [2, 5, 8])
 def test_device_mvn_factor_any_dimension(pkg, d):
     """smc_proposal_factor_device for d != 3 (the methanation model has d = 5; SMC_MAX_DIM = 8) on a badly scaled, correlated

@@ -25,6 +25,24 @@ __device__ __forceinline__ double lean_div1(double a, double b) {  // one Newton
     double rem = fma(-b, q, a);
     return fma(rem, r, q);
 }
+__device__ __forceinline__ double lean_div5(double a, double b) {  // Newton step on the quotient beside the one on r: 5-op chain
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e = fma(-b, r0, 1.0);
+    const double q0 = a * r0;
+    const double r = fma(r0, e, r0);
+    const double q1 = fma(q0, e, q0);
+    const double rem = fma(-b, q1, a);
+    return fma(rem, r, q1);
+}
+__global__ void k_div5(const double* a, const double* b, double* q5, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q5[i] = lean_div5(a[i], b[i]);
+}
+__global__ void k_lean5chain(double* out, int iters) {
+    double x = 1.0 + threadIdx.x * 1e-3;
+    for (int i = 0; i < iters; ++i) { x = lean_div5(1.7, x + 0.3); x = lean_div5(1.7, x + 0.3); }
+    out[threadIdx.x] = x;
+}
 __global__ void k_div(const double* a, const double* b, double* q_ieee, double* q_lean, double* q_lean1, double* rcp, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -103,6 +121,25 @@ int main() {
     }
     printf("n=%d  device a/b != host a/b: %ld   lean(2 newton) mismatches: %ld   lean(1 newton) mismatches: %ld   max |rcp*b-1| = %.3e (2^%.1f)\n",
            n, mis_ieee, mis1, mis2, maxr, std::log2(maxr));
+    {   // the 5-op variant (the product's lean_div this round): wide-exponent operands above, then operand pairs shaped like
+        // the Michaelis-Menten right-hand side: a = -Vmax*S, b = Km + S with Vmax, Km in (0,10), S in (0, 2]
+        double* q5; hipMalloc(&q5, n * 8);
+        std::vector<double> h5(n);
+        k_div5<<<n / 256, 256>>>(da, db, q5, n);
+        hipMemcpy(h5.data(), q5, n * 8, hipMemcpyDeviceToHost);
+        long mis5 = 0;
+        for (int i = 0; i < n; ++i) if (h5[i] != a[i] / b[i]) mis5++;
+        std::uniform_real_distribution<double> U10(0.0, 10.0), U2(1e-9, 2.0);
+        std::vector<double> a2(n), b2(n);
+        for (int i = 0; i < n; ++i) { const double Vm = U10(g), Km = (i & 1) ? U10(g) : U10(g) * 1e-3, S = U2(g); a2[i] = -Vm * S; b2[i] = Km + S; }
+        hipMemcpy(da, a2.data(), n * 8, hipMemcpyHostToDevice); hipMemcpy(db, b2.data(), n * 8, hipMemcpyHostToDevice);
+        k_div5<<<n / 256, 256>>>(da, db, q5, n);
+        hipMemcpy(h5.data(), q5, n * 8, hipMemcpyDeviceToHost);
+        long mis5b = 0;
+        for (int i = 0; i < n; ++i) if (h5[i] != a2[i] / b2[i]) mis5b++;
+        printf("lean 5-op chain: mismatches vs host a/b: %ld of %d (wide exponents), %ld of %d (RHS-shaped operands)\n", mis5, n, mis5b, n);
+        hipMemcpy(da, a.data(), n * 8, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
+    }
     // FMA peak
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     double* out; hipMalloc(&out, 256 * 8 * 4096 * 8);
@@ -123,6 +160,7 @@ int main() {
         hipEventElapsedTime(&ms, e0, e1); printf("%s: %.2f ns\n", label, ms * 1e6 / ((per) * 100000.0)); } while (0)
     TIME(k_lean2chain, "dependent (add + lean 2-newton div)", 2);
     TIME(k_lean1chain, "dependent (add + lean 1-newton div)", 2);
+    TIME(k_lean5chain, "dependent (add + lean 5-op-chain div)", 2);
     TIME(k_powchain, "dependent (pow_minus_fifth + mul)", 2);
     TIME(k_libpowchain, "dependent (ocml pow + mul)", 2);
     TIME(k_addchain, "dependent add/mul op", 4);
