@@ -130,29 +130,38 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
     bool live = false;              // this lane holds a running item
     int64_t out_idx = 0;            // e*n + p of the running item
     double *pred_item = nullptr;
-    unsigned long long q_lo = 0, q_hi = 0;  // wave-uniform: the wave's current chunk
-    bool drained = false;           // wave-uniform: the global queue is empty
+    // Loop control lives in SGPRs (the chunk bounds come back from the atomic through v_readfirstlane, n_idle from a
+    // ballot): every branch of the scheduling logic is a scalar branch.  In round 1 q_lo / q_hi travelled through a
+    // __shfl, the compiler had to treat `q_lo == q_hi` and `drained` as divergent and wrapped the whole loop in exec-mask
+    // bookkeeping: 0.19 us per iteration on top of the 0.41 us of an attempt for a wave that runs alone (the stragglers of
+    // the early tempering steps), measured with tools/tail_latency.py.
+    unsigned long long q_lo = 0, q_hi = 0;  // the wave's current chunk
+    bool drained = false;                   // the global queue is empty
 
     for (;;) {
-        const unsigned long long idle_mask = __ballot(!live);
-        const int n_idle = __popcll(idle_mask);
-        if (!drained && (n_idle >= kRefillAt || n_idle == kWave)) {
+        const unsigned long long live_mask = __ballot(live);
+        const int n_idle = kWave - __popcll(live_mask);
+        bool handed_out = false;
+        if (!drained && n_idle >= kRefillAt) {
             if (q_lo == q_hi) {  // next chunk: one atomic per wave and kChunk items
                 unsigned long long b = 0;
                 if (lane == 0) b = atomicAdd(a.queue, (unsigned long long)kChunk);
-                b = __shfl(b, 0);
-                q_lo = b;
-                q_hi = (b + kChunk < n_items) ? b + kChunk : n_items;
+                const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+                const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+                q_lo = ((unsigned long long)b_hi << 32) | b_lo;
+                q_hi = (q_lo + kChunk < n_items) ? q_lo + kChunk : n_items;
                 if (q_lo >= n_items) {
                     drained = true;
                     q_lo = q_hi = 0;
                 }
             }
             if (!drained) {
+                const unsigned long long idle_mask = ~live_mask;
                 const unsigned long long avail = q_hi - q_lo;
                 const int my = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
                                                               __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
                 const int take = (unsigned long long)n_idle < avail ? n_idle : (int)avail;
+                handed_out = true;
                 if (!live && my < take) {
                     const unsigned long long item = q_lo + my;
                     const unsigned long long grp = item >> 6;            // 64-item group
@@ -203,18 +212,25 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
             }
             break;
         }
-        if (__ballot(live) == 0ull) continue;
-        if (live) {
-            const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
-            if (st != 0) {
-                const bool ok = (st == 1) && (it.i_out == n_t);
-                a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
-                a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
-                if (WRITE_PRED && !ok)
-                    for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
-                live = false;
+        if (handed_out && __ballot(live) == 0ull) continue;   // otherwise fewer than kRefillAt lanes are idle: some lane is live
+        // attempts of the live lanes until kRefillAt lanes are idle again: a tight inner loop (item state stays in its
+        // registers, one ballot and one scalar branch per attempt) - the scheduling logic above runs once per hand-out,
+        // not once per attempt
+        int idle_now;
+        do {
+            if (live) {
+                const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
+                if (st != 0) {
+                    const bool ok = (st == 1) && (it.i_out == n_t);
+                    a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
+                    a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
+                    if (WRITE_PRED && !ok)
+                        for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
+                    live = false;
+                }
             }
-        }
+            idle_now = kWave - __popcll(__ballot(live));
+        } while (idle_now < kRefillAt);
     }
 }
 

@@ -63,12 +63,14 @@ namespace smc {
 //   lean_div6  rcp -> e -> r -> q = a*r -> rem -> result: six dependent operations, six instructions.  The product path.
 //   lean_div5  the Newton step applied to the QUOTIENT, q1 = q0 + q0*e with q0 = a*r0, beside the one on the reciprocal:
 //              rcp -> e -> q1 -> rem -> result, five dependent operations but seven instructions.  Tried this round to
-//              shorten the serial chain of a stiff solve, and NOT adopted: alone on the GPU a 12 562-attempt solve takes
-//              0.419 us per attempt with lean_div6 and 0.460 us with lean_div5 (+9.9 %; tools/attempt_probe.hip, both
-//              variants alternating in one process, profiles/r02_attempt_probe.log), and the bulk loop is 2 % slower too
-//              (profiles/r02_ab_lean_div.log).  The attempt is not a pure latency chain: ~200 vector instructions at >= 4
-//              issue cycles each are ~2/3 of its ~1000 cycles, so an extra instruction per division costs more than the
-//              dependent operation it removes.  Kept as a template option for the probe only.
+//              shorten the serial chain of a stiff solve, and NOT adopted: no consistent gain.  A 12 562-attempt solve
+//              alone on the GPU (tools/attempt_probe.hip, both variants alternating in one process) came out at
+//              0.419 / 0.460 us per attempt (six / five) on two boxes and at 0.462 / 0.448 on two others - the time of
+//              a lone wave moves by +-10 % with where it lands and what else the chip is doing (same probe: 0.41 ... 0.52
+//              us with 0 ... 250 busy blocks beside it, not monotonic) - and the bulk loop was 2 % slower with it
+//              (profiles/r02_attempt_probe.log, r02_ab_lean_div.log).  The attempt is not a pure latency chain: ~200
+//              vector instructions at >= 4 issue cycles each are ~2/3 of its ~1000 cycles, so an extra instruction per
+//              division costs about what the dependent operation it removes saves.  Kept as a template option for the probe.
 // No scaling and no special-case fix-up, so they are only used inside rk_attempt_core<DIV != 0>, whose caller
 // re-runs the whole attempt with IEEE division whenever the result is not finite; quotients in the
 // denormal range may differ from IEEE in the last bits (they sit > 280 orders below atol).

@@ -5,13 +5,16 @@ misspelling is the reference's).  Same names, defaults and import-time side effe
 directory (:137-214).  NB: like the reference, only the FIRST n_data rows of the sliced table are converted
 (the loops run over range(n_data) although the slice holds datafin-datastart+1 rows)."""
 import numpy as np
-import pandas as pd
+
+from smc_lt_amd import methanation as _M
+from smc_lt_amd.driver import SMCSettings as _SMCSettings
 
 np.random.seed(20250205)
+_s = _SMCSettings()
 
 n_state = 9
 num_model_params = 8
-est_params_list = [1, 1, 1, 1, 0, 0, 0, 0, 1]
+est_params_list = list(_M.EST_PARAMS_LIST)
 num_est_params = np.sum(est_params_list)
 taylor = False
 normal_pred = False
@@ -24,20 +27,19 @@ est_position_set = set(est_position)
 uni_list_set = set(uni_list)
 def_set = uni_list_set - est_position_set
 
-NX = 51
-datalist = [0, 2, 5, 6, 8, 9, 10, 11, 13, 14, 15, 16, 17, 19, 20, 21, 22, 25, 26, 27, 28, 31, 35, 38, 40, 45, 49, 52, 55, 58]
+NX = _M.NX
+datalist = list(_M.DATALIST)
 datastart = datalist[0]
 datafin = datalist[-1]
 n_data = len(datalist)
 
-sigma_true = 5
-baseparams = np.array([13.04, 52.2e3, 1.147e5, 96.7e3, 23.34, -6, 0.72, -2.51e3])
+sigma_true = _M.SIGMA_TRUE
+baseparams = _M.BASEPARAMS.copy()
 baseparams_withsigma = np.append(baseparams, sigma_true)
 use_params = np.append(baseparams, sigma_true)
-high_k = [25, 1, 30, 2, 1, -2, 1, -2, 2]
-low_k = [4, 1, 4, 1, 1, -2, 1, -2, 0.9]
-high_limit = use_params + use_params * np.array(high_k)
-low_limit = use_params - use_params * np.array(low_k)
+high_k = list(_M.HIGH_K)
+low_k = list(_M.LOW_K)
+low_limit, high_limit, _ = _M.prior_box()
 high_limit_array = np.array([high_limit[i] for i in est_position])
 low_limit_array = np.array([low_limit[i] for i in est_position])
 
@@ -46,7 +48,7 @@ sc = np.array([-4, -1, 1, 2, 0])
 Dz = 0.95e-5
 rhos = 5075
 Hr = -164940
-R = 8.3144589
+R = _M.GAS_R
 Rr = 0.01 / 2
 S = pi * Rr ** 2
 Cpg = 2800
@@ -62,22 +64,23 @@ li = [1] * (6 * NX) + [0] * NX
 at = 0.001
 atol = [at] * (7 * NX)
 
+# SMC hyper-parameters (:107-132): the engine's own defaults, so that the two cannot drift apart
 n_cores = 30
-n_particle = 1000
+n_particle = _s.n_particle
 inv_Np = 1 / n_particle
-ess_limit = 0.5
-mhstep_factor = 0.5
-mhstep_factor_cov = 0.5
-ad_mhstep_num = 20
-mhstep_num = 5
+ess_limit = _s.ess_limit
+mhstep_factor = _s.mhstep_factor
+mhstep_factor_cov = _s.mhstep_factor_cov
+ad_mhstep_num = _s.ad_mhstep_num
+mhstep_num = _s.mhstep_num
 mhstep_ratio = 1.0
-r_threshold = 0.5
-r_threshold_f = 0.7
-r_threshold_min = 0.1
-d_gamma_max = 1
-gm_reduction_itr = 80
-gm_reduction_rate = 0.7
-itr_max = 50
+r_threshold = _s.r_threshold
+r_threshold_f = _s.r_threshold_f
+r_threshold_min = _s.r_threshold_min
+d_gamma_max = _s.d_gamma_max
+gm_reduction_itr = _s.gm_reduction_itr
+gm_reduction_rate = _s.gm_reduction_rate
+itr_max = _s.itr_max
 n_hist = 50
 fig_dimen = int(n_state * 100 + 11)
 w_cov = np.ones((num_est_params, num_est_params))
@@ -85,42 +88,18 @@ for _i in range(num_est_params):
     w_cov[_i, :] = mhstep_factor_cov
     w_cov[_i, _i] = mhstep_factor
 
-info_df = pd.read_csv('methanation_data/information.csv').fillna(0)
-information = info_df.iloc[datastart:datafin + 1].values
-
-catag = information[:, 2]
-reactorlength = information[:, 4]
-T_jacket = information[:, 5]
-void_fraction = information[:, 6]
-T_in = information[:, 7]
-P_total = information[:, 9]
-in_flow_a, in_flow_b, in_flow_c, in_flow_d, in_flow_e = (information[:, _k] for _k in (10, 11, 12, 14, 15))
-in_flow_total = information[:, 16]
-out_flow_a, out_flow_b, out_flow_c, out_flow_d, out_flow_e = (information[:, _k] for _k in (17, 18, 19, 21, 22))
-out_flow_total = information[:, 23]
-out_molf_a, out_molf_b, out_molf_c, out_molf_d, out_molf_e = (information[:, _k] for _k in (24, 25, 26, 28, 29))
-
-Ca_in, Cb_in, Cc_in, Cd_in, Ce_in = (np.zeros(n_data) for _ in range(5))
-Xa_out, Xb_out, Xc_out, Xd_out, Xe_out = (np.zeros(n_data) for _ in range(5))
-u_in = np.zeros(n_data)
-sccm = np.zeros(n_data)
-void = np.zeros(n_data)
-Fa_out, Fb_out, Fc_out, Fd_out, Fe_out = (np.zeros(n_data) for _ in range(5))
-for _i in range(0, n_data):
-    T_in[_i] = T_in[_i] + 273
-    _tot = in_flow_a[_i] + in_flow_b[_i] + in_flow_c[_i] + in_flow_d[_i] + in_flow_e[_i]
-    Ca_in[_i] = (P_total[_i] * 1e6 + 101325) / R / T_in[_i] * in_flow_a[_i] / _tot
-    Cb_in[_i] = (P_total[_i] * 1e6 + 101325) / R / T_in[_i] * in_flow_b[_i] / _tot
-    Cc_in[_i] = (P_total[_i] * 1e6 + 101325) / R / T_in[_i] * in_flow_c[_i] / _tot
-    Cd_in[_i] = (P_total[_i] * 1e6 + 101325) / R / T_in[_i] * in_flow_d[_i] / _tot
-    Ce_in[_i] = (P_total[_i] * 1e6 + 101325) / R / T_in[_i] * in_flow_e[_i] / _tot
-    Xa_out[_i], Xb_out[_i], Xc_out[_i], Xd_out[_i], Xe_out[_i] = (out_molf_a[_i], out_molf_b[_i], out_molf_c[_i],
-                                                                     out_molf_d[_i], out_molf_e[_i])
-    T_jacket[_i] = T_jacket[_i] + 273
-    catag[_i] = catag[_i] / 1000
-    reactorlength[_i] = reactorlength[_i] / 1000
-    sccm[_i] = in_flow_total[_i]
-    void[_i] = void_fraction[_i]
-    Fa_out[_i], Fb_out[_i], Fc_out[_i], Fd_out[_i], Fe_out[_i] = (out_flow_a[_i], out_flow_b[_i], out_flow_c[_i],
-                                                                     out_flow_d[_i], out_flow_e[_i])
-u_in = in_flow_total * 1.667e-8 / S * (101325 * T_in) / ((P_total * 1e6 + 101325) * 298)
+# inlet conditions (:137-214): computed in ONE place, smc_lt_amd.methanation.settings_arrays; republished here under the
+# reference's module-level names
+_A = _M.settings_arrays('methanation_data/information.csv')
+information = _A["information"]
+(catag, reactorlength, T_jacket, void_fraction, T_in, P_total) = (_A[k] for k in
+                                                                  ("catag", "reactorlength", "T_jacket", "void_fraction", "T_in", "P_total"))
+in_flow_a, in_flow_b, in_flow_c, in_flow_d, in_flow_e = (_A[f"in_flow_{k}"] for k in "abcde")
+in_flow_total = _A["in_flow_total"]
+out_flow_a, out_flow_b, out_flow_c, out_flow_d, out_flow_e = (_A[f"out_flow_{k}"] for k in "abcde")
+out_flow_total = _A["out_flow_total"]
+out_molf_a, out_molf_b, out_molf_c, out_molf_d, out_molf_e = (_A[f"out_molf_{k}"] for k in "abcde")
+Ca_in, Cb_in, Cc_in, Cd_in, Ce_in = (_A[f"C{k}_in"] for k in "abcde")
+Xa_out, Xb_out, Xc_out, Xd_out, Xe_out = (_A[f"X{k}_out"] for k in "abcde")
+Fa_out, Fb_out, Fc_out, Fd_out, Fe_out = (_A[f"F{k}_out"] for k in "abcde")
+u_in, sccm, void = _A["u_in"], _A["sccm"], _A["void"]

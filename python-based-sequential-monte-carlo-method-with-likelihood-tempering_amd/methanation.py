@@ -89,28 +89,48 @@ GAS_R = 8.3144589
 TUBE_AREA = np.pi * (0.01 / 2) ** 2
 
 
-def load_conditions(information_csv: str) -> dict:
-    """Inlet conditions of the n_data experiments from the information table (methanation_set_conditon.py:137-214):
-    concentrations from pressure / temperature / inlet flows, Kelvin temperatures, metres, superficial velocity.
-    As in the reference only the first n_data rows of the datastart..datafin slice are converted (:139,188-212)."""
+# information.csv columns the settings module reads (methanation_set_conditon.py:141-186)
+_INFO_COLS = {"catag": 2, "reactorlength": 4, "T_jacket": 5, "void_fraction": 6, "T_in": 7, "P_total": 9,
+              "in_flow_a": 10, "in_flow_b": 11, "in_flow_c": 12, "in_flow_d": 14, "in_flow_e": 15, "in_flow_total": 16,
+              "out_flow_a": 17, "out_flow_b": 18, "out_flow_c": 19, "out_flow_d": 21, "out_flow_e": 22, "out_flow_total": 23,
+              "out_molf_a": 24, "out_molf_b": 25, "out_molf_c": 26, "out_molf_d": 28, "out_molf_e": 29}
+
+
+def settings_arrays(information_csv: str) -> dict:
+    """Every array the reference's settings module derives from the information table
+    (methanation_set_conditon.py:137-214), under the reference's names - the ONE place where that conversion lives (the
+    drop-in module dropin/methanation_set_conditon.py only republishes these under module-level names).
+    Column views of the datastart..datafin slice (:139-186); then, for the first n_data rows only, as the reference's
+    loop does (:188-212): inlet concentrations C = (P_gauge*1e6 + 101325) / R / T_in * flow / sum(flows), Kelvin
+    temperatures, metres and kilograms; u_in over the whole slice (:214).  Element for element the reference's
+    arithmetic (same operations in the same order, so the values are bit-equal to the loop's)."""
     import pandas as pd
-    info = pd.read_csv(information_csv).fillna(0).iloc[DATALIST[0]:DATALIST[-1] + 1].values
+    information = pd.read_csv(information_csv).fillna(0).iloc[DATALIST[0]:DATALIST[-1] + 1].values
     n_data = len(DATALIST)
-    T_in, T_jacket, length = info[:, 7].copy(), info[:, 5].copy(), info[:, 4].copy()
-    P_total, flows, total = info[:, 9], [info[:, k] for k in (10, 11, 12, 14, 15)], info[:, 16]
-    conc = [np.zeros(n_data) for _ in range(5)]
-    void = np.zeros(n_data)
-    for i in range(n_data):
-        T_in[i] = T_in[i] + 273
-        tot = flows[0][i] + flows[1][i] + flows[2][i] + flows[3][i] + flows[4][i]
-        for k in range(5):
-            conc[k][i] = (P_total[i] * 1e6 + 101325) / GAS_R / T_in[i] * flows[k][i] / tot
-        T_jacket[i] = T_jacket[i] + 273
-        length[i] = length[i] / 1000
-        void[i] = info[i, 6]
-    u_in = total * 1.667e-8 / TUBE_AREA * (101325 * T_in) / ((P_total * 1e6 + 101325) * 298)      # :214
-    return dict(Ca_in=conc[0], Cb_in=conc[1], Cc_in=conc[2], Cd_in=conc[3], Ce_in=conc[4], T_in=T_in, T_jacket=T_jacket,
-                u_in=u_in, void=void, reactorlength=length, n_data=n_data)
+    a = {"information": information, "n_data": n_data}
+    for name, col in _INFO_COLS.items():
+        a[name] = information[:, col]                       # views: the in-place unit conversions below show through
+    h = slice(0, n_data)
+    a["T_in"][h] = a["T_in"][h] + 273
+    tot = a["in_flow_a"][h] + a["in_flow_b"][h] + a["in_flow_c"][h] + a["in_flow_d"][h] + a["in_flow_e"][h]
+    for k in "abcde":
+        a[f"C{k}_in"] = (a["P_total"][h] * 1e6 + 101325) / GAS_R / a["T_in"][h] * a[f"in_flow_{k}"][h] / tot
+        a[f"X{k}_out"] = a[f"out_molf_{k}"][h].copy()
+        a[f"F{k}_out"] = a[f"out_flow_{k}"][h].copy()
+    a["T_jacket"][h] = a["T_jacket"][h] + 273
+    a["catag"][h] = a["catag"][h] / 1000
+    a["reactorlength"][h] = a["reactorlength"][h] / 1000
+    a["sccm"] = a["in_flow_total"][h].copy()
+    a["void"] = a["void_fraction"][h].copy()
+    a["u_in"] = a["in_flow_total"] * 1.667e-8 / TUBE_AREA * (101325 * a["T_in"]) / ((a["P_total"] * 1e6 + 101325) * 298)
+    return a
+
+
+def load_conditions(information_csv: str) -> dict:
+    """The inlet conditions the DAE needs, from settings_arrays()."""
+    a = settings_arrays(information_csv)
+    return dict(Ca_in=a["Ca_in"], Cb_in=a["Cb_in"], Cc_in=a["Cc_in"], Cd_in=a["Cd_in"], Ce_in=a["Ce_in"], T_in=a["T_in"],
+                T_jacket=a["T_jacket"], u_in=a["u_in"], void=a["void"], reactorlength=a["reactorlength"], n_data=a["n_data"])
 
 
 def initial_guess(cond: dict) -> np.ndarray:
@@ -125,11 +145,15 @@ def initial_guess(cond: dict) -> np.ndarray:
     return guess
 
 
+HIGH_K = [25, 1, 30, 2, 1, -2, 1, -2, 2]          # :59
+LOW_K = [4, 1, 4, 1, 1, -2, 1, -2, 0.9]           # :60
+
+
 def prior_box():
     """(low_limit, high_limit, est_position) of the uniform priors (methanation_set_conditon.py:22,59-70)."""
     use = np.append(BASEPARAMS, SIGMA_TRUE)
-    high = use + use * np.array([25, 1, 30, 2, 1, -2, 1, -2, 2])
-    low = use - use * np.array([4, 1, 4, 1, 1, -2, 1, -2, 0.9])
+    high = use + use * np.array(HIGH_K)
+    low = use - use * np.array(LOW_K)
     return low, high, [i for i, x in enumerate(EST_PARAMS_LIST) if x == 1]
 
 
