@@ -309,7 +309,10 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
         hipLaunchKernelGGL(dae_kernel, dim3((unsigned)(nslots / 64)), dim3(64), 0, 0, dws, nslots, dp, dy0, n_solves, tf,
                            rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
     } else if (!v2) {
-        int64_t nwaves = (int64_t)prop.multiProcessorCount * 4;
+        // one wave per SIMD is all that fits (512 VGPRs and 38.8 KB of LDS per wave); SMC_METH_WAVES_PER_CU < 4 thins the grid
+        // for the occupancy-scaling measurement of profiles/r02_k8_occupancy.md
+        const int wpc = getenv("SMC_METH_WAVES_PER_CU") ? atoi(getenv("SMC_METH_WAVES_PER_CU")) : 4;
+        int64_t nwaves = (int64_t)prop.multiProcessorCount * (wpc >= 1 && wpc <= 4 ? wpc : 4);
         if (nwaves > n_solves) nwaves = n_solves;
         hipLaunchKernelGGL(dae_elem_kernel, dim3((unsigned)nwaves), dim3(64), kLdsDoubles * sizeof(double), 0, dp, dy0,
                            n_solves, tf, rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
