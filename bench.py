@@ -198,6 +198,7 @@ def launch_ranks(n):
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=os.environ.get("MASTER_PORT", "29500"), SMC_BENCH_RDZV=rdzv)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # this pool's driver only supports dmabuf IPC (RCCL needs it)
             out = None if r == 0 else sys.stderr            # one JSON line on stdout: rank 0's
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
         rc = 0

@@ -4,6 +4,8 @@
 // fixed order + a single-block final pass), so results are reproducible run to run.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstring>
 
 #include "philox.h"
@@ -182,11 +184,12 @@ __global__ void __launch_bounds__(kScanBlock) ess_partial_kernel(const double *_
         }
     }
 }
-// sums nvals interleaved values over np partial rows, in row order
+// sums nvals interleaved values over np partial rows: one block per value (round 1 had ONE block walk through all values,
+// 18.7 us for 32 values x 2048 rows - a third of an ESS pass); the order of additions within a value is unchanged
 __global__ void __launch_bounds__(kScanBlock) sum_rows_final_kernel(const double *__restrict__ partials, int np,
                                                                     int nvals, double *__restrict__ out) {
     __shared__ double lds[4];
-    for (int v = 0; v < nvals; ++v) {
+    for (int v = blockIdx.x; v < nvals; v += gridDim.x) {
         double s = 0.0;
         for (int i = threadIdx.x; i < np; i += blockDim.x) s += partials[(size_t)i * nvals + v];
         s = block_sum(s, lds);
@@ -592,8 +595,9 @@ __global__ void resample_stale_rows_kernel(const double *__restrict__ src_theta,
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline int reduce_grid(int64_t n) {
+    static const int cap = getenv("SMC_REDUCE_BLOCKS") ? atoi(getenv("SMC_REDUCE_BLOCKS")) : 512;   // 2 blocks per CU: measured best of 256..2048 (profiles/r02_ess_bench.log); the block epilogue (32 block sums for 16 candidates) dominated at 2048
     int64_t g = (n + kScanBlock - 1) / kScanBlock;
-    if (g > 2048) g = 2048;  // 256 CUs x 8: grid-stride the rest
+    if (g > cap) g = cap;    // grid-stride the rest
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -643,7 +647,7 @@ void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const do
         hipLaunchKernelGGL((ess_partial_kernel<16>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
                            c->d_partials);
     }
-    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, 2 * K, d_out);
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(2 * K), dim3(kScanBlock), 0, c->stream, c->d_partials, g, 2 * K, d_out);
 }
 int ess_padded_k(int k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 8 ? 8 : 16; }
 
@@ -652,7 +656,7 @@ void launch_moment_sums(smc_ctx *c, double *d_out) {
     const int g = reduce_grid(c->n_local);
     hipLaunchKernelGGL(moment_sum_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, F.theta, F.stride, c->n_local,
                        c->dim, c->d_partials);
-    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, c->dim, d_out);
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(c->dim), dim3(kScanBlock), 0, c->stream, c->d_partials, g, c->dim, d_out);
 }
 void launch_moment_centered(smc_ctx *c, const double *mean, double *d_out) {
     ParticleSet &F = c->set[SMC_SET_FILT];
@@ -662,7 +666,7 @@ void launch_moment_centered(smc_ctx *c, const double *mean, double *d_out) {
     const int npair = c->dim * (c->dim + 1) / 2;
     hipLaunchKernelGGL(moment_centered_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, F.theta, F.stride, c->n_local,
                        c->dim, m, (const double *)nullptr, 1.0, c->d_partials);
-    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(npair), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
 }
 void launch_moment_centered_dev(smc_ctx *c, const double *d_sums, double *d_out) {
     ParticleSet &F = c->set[SMC_SET_FILT];
@@ -671,7 +675,7 @@ void launch_moment_centered_dev(smc_ctx *c, const double *d_sums, double *d_out)
     const int npair = c->dim * (c->dim + 1) / 2;
     hipLaunchKernelGGL(moment_centered_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, F.theta, F.stride, c->n_local,
                        c->dim, m, d_sums, (double)c->n_global, c->d_partials);
-    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
+    hipLaunchKernelGGL(sum_rows_final_kernel, dim3(npair), dim3(kScanBlock), 0, c->stream, c->d_partials, g, npair, d_out);
 }
 void launch_mh_transform(smc_ctx *c, const double *d_mom, const double *d_sums, const double *w_cov, double *d_shift,
                          double *d_cov, double *d_xform) {
