@@ -222,14 +222,15 @@ __global__ void __launch_bounds__(kScanBlock) moment_centered_kernel(const doubl
                                                                      const double *__restrict__ dev_sums, double n_div,
                                                                      double *__restrict__ partials) {
     __shared__ double lds[4];
+    __shared__ double s_mu[SMC_MAX_DIM];   // (writing the device-side mean into the by-value argument would move it to scratch)
     double acc[SMC_MAX_DIM * (SMC_MAX_DIM + 1) / 2];
     const int npair = d * (d + 1) / 2;
-    if (dev_sums)
-        for (int c = 0; c < d; ++c) mean.m[c] = dev_sums[c] / n_div;
+    if ((int)threadIdx.x < d) s_mu[threadIdx.x] = dev_sums ? dev_sums[threadIdx.x] / n_div : mean.m[threadIdx.x];
+    __syncthreads();
     for (int k = 0; k < npair; ++k) acc[k] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         double x[SMC_MAX_DIM];
-        for (int c = 0; c < d; ++c) x[c] = theta[c * stride + i] - mean.m[c];
+        for (int c = 0; c < d; ++c) x[c] = theta[c * stride + i] - s_mu[c];
         int k = 0;
         for (int a = 0; a < d; ++a)
             for (int b = a; b < d; ++b) acc[k++] += x[a] * x[b];
@@ -255,13 +256,18 @@ struct WCov {
 //   sums == nullptr  carried: `mom` = [sum y (d) | sum y y^T (upper)] with y = x - shift, accumulated by the accept kernel of the
 //                    previous iteration about the mean of the iteration before (so |E y| << spread: no cancellation to speak
 //                    of): cov = E[y y^T] - E[y] E[y]^T, and the shift moves on to the new mean.
+template <int D>
 __global__ void mh_transform_kernel(const double *__restrict__ mom, const double *__restrict__ sums, double n_global, WCov wcov,
-                                    int d, double *__restrict__ shift_io, double *__restrict__ cov_out,
+                                    double *__restrict__ shift_io, double *__restrict__ cov_out,
                                     double *__restrict__ xform_out) {
+    // D is a compile-time constant and every loop below is unrolled, so A and V live in registers: the first version, with
+    // run-time d and SMC_MAX_DIM arrays in scratch, took 23 us per call - on the critical path of every iteration
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double A[SMC_MAX_DIM][SMC_MAX_DIM], V[SMC_MAX_DIM][SMC_MAX_DIM];
+    constexpr int d = D;
+    double A[D][D], V[D][D];
     const double inv_n = 1.0 / n_global;     // np.true_divide(1, fact), then c *= that (np.cov)
-    double ey[SMC_MAX_DIM];
+    double ey[D];
+#pragma unroll
     for (int a = 0; a < d; ++a) {
         if (sums) {
             ey[a] = 0.0;
@@ -272,70 +278,88 @@ __global__ void mh_transform_kernel(const double *__restrict__ mom, const double
         }
     }
     const double *cent = sums ? mom : mom + d;
-    int k = 0;
+    {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < d; ++a)
+#pragma unroll
+            for (int b = a; b < d; ++b) {
+                const double v = cent[k++] * inv_n - ey[a] * ey[b];
+                A[a][b] = v * wcov.w[a * d + b];
+                A[b][a] = v * wcov.w[b * d + a];
+            }
+    }
+#pragma unroll
     for (int a = 0; a < d; ++a)
-        for (int b = a; b < d; ++b) {
-            const double v = cent[k++] * inv_n - ey[a] * ey[b];
-            A[a][b] = v * wcov.w[a * d + b];
-            A[b][a] = v * wcov.w[b * d + a];
-        }
-    for (int a = 0; a < d; ++a)
+#pragma unroll
         for (int b = 0; b < d; ++b) {
             cov_out[a * d + b] = A[a][b];
             V[a][b] = (a == b) ? 1.0 : 0.0;
         }
     // w_cov is symmetric in the reference (Micmem_settings.py:94-97); should a caller pass an asymmetric one, the
     // decomposition below is that of the symmetric part
+#pragma unroll
     for (int a = 0; a < d; ++a)
+#pragma unroll
         for (int b = a + 1; b < d; ++b) A[a][b] = A[b][a] = 0.5 * (A[a][b] + A[b][a]);
+#pragma unroll 1
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0, diag = 0.0;
+#pragma unroll
         for (int p = 0; p < d; ++p) {
             diag += A[p][p] * A[p][p];
+#pragma unroll
             for (int q = p + 1; q < d; ++q) off += A[p][q] * A[p][q];
         }
         if (!(off > 1e-34 * diag)) break;   // also leaves on NaN
+#pragma unroll
         for (int p = 0; p < d; ++p)
+#pragma unroll
             for (int q = p + 1; q < d; ++q) {
                 const double apq = A[p][q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-                const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int r = 0; r < d; ++r) {   // A <- A J
-                    const double arp = A[r][p], arq = A[r][q];
-                    A[r][p] = cs * arp - sn * arq;
-                    A[r][q] = sn * arp + cs * arq;
-                }
-                for (int r = 0; r < d; ++r) {   // A <- J^T A
-                    const double apr = A[p][r], aqr = A[q][r];
-                    A[p][r] = cs * apr - sn * aqr;
-                    A[q][r] = sn * apr + cs * aqr;
-                }
-                for (int r = 0; r < d; ++r) {
-                    const double vrp = V[r][p], vrq = V[r][q];
-                    V[r][p] = cs * vrp - sn * vrq;
-                    V[r][q] = sn * vrp + cs * vrq;
+                if (apq != 0.0) {
+                    const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                    const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                    for (int r = 0; r < d; ++r) {   // A <- A J
+                        const double arp = A[r][p], arq = A[r][q];
+                        A[r][p] = cs * arp - sn * arq;
+                        A[r][q] = sn * arp + cs * arq;
+                    }
+#pragma unroll
+                    for (int r = 0; r < d; ++r) {   // A <- J^T A
+                        const double apr = A[p][r], aqr = A[q][r];
+                        A[p][r] = cs * apr - sn * aqr;
+                        A[q][r] = sn * apr + cs * aqr;
+                    }
+#pragma unroll
+                    for (int r = 0; r < d; ++r) {
+                        const double vrp = V[r][p], vrq = V[r][q];
+                        V[r][p] = cs * vrp - sn * vrq;
+                        V[r][q] = sn * vrp + cs * vrq;
+                    }
                 }
             }
     }
-    int order[SMC_MAX_DIM];
-    for (int i = 0; i < d; ++i) order[i] = i;
-    for (int i = 0; i < d; ++i)          // selection sort by |lambda| descending (svd order)
-        for (int j = i + 1; j < d; ++j)
-            if (fabs(A[order[j]][order[j]]) > fabs(A[order[i]][order[i]])) {
-                const int t = order[i];
-                order[i] = order[j];
-                order[j] = t;
-            }
-    for (int i = 0; i < d; ++i) {
-        const int e = order[i];
-        const double sv = sqrt(fabs(A[e][e]));
-        int big = 0;
+    // rows of the factor by |lambda| descending (svd order): rank of column e = number of columns that come before it
+#pragma unroll
+    for (int e = 0; e < d; ++e) {
+        const double le = fabs(A[e][e]);
+        int rank = 0;
+#pragma unroll
+        for (int f = 0; f < d; ++f) {
+            const double lf = fabs(A[f][f]);
+            rank += (lf > le || (lf == le && f < e)) ? 1 : 0;
+        }
+        const double sv = sqrt(le);
+        double big = V[0][e];
+#pragma unroll
         for (int c = 1; c < d; ++c)
-            if (fabs(V[c][e]) > fabs(V[big][e])) big = c;
-        const double sg = (V[big][e] < 0.0) ? -1.0 : 1.0;
-        for (int c = 0; c < d; ++c) xform_out[i * d + c] = sv * (sg * V[c][e]);
+            if (fabs(V[c][e]) > fabs(big)) big = V[c][e];
+        const double sg = (big < 0.0) ? -1.0 : 1.0;
+#pragma unroll
+        for (int c = 0; c < d; ++c) xform_out[rank * d + c] = sv * (sg * V[c][e]);
     }
 }
 
@@ -594,8 +618,11 @@ __global__ void resample_stale_rows_kernel(const double *__restrict__ src_theta,
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static inline int reduce_grid(int64_t n) {
-    static const int cap = getenv("SMC_REDUCE_BLOCKS") ? atoi(getenv("SMC_REDUCE_BLOCKS")) : 512;   // 2 blocks per CU: measured best of 256..2048 (profiles/r02_ess_bench.log); the block epilogue (32 block sums for 16 candidates) dominated at 2048
+// blocks of a grid-stride reduction: 2048 (8 per CU) for the passes that only stream, 512 (2 per CU) for the ESS pass, whose
+// block epilogue - 2K block sums for K candidates - dominated at 2048 (measured 256 .. 2048: profiles/r02_ess_bench.log)
+static inline int reduce_grid(int64_t n, int cap = 2048) {
+    static const int ess_cap = getenv("SMC_REDUCE_BLOCKS") ? atoi(getenv("SMC_REDUCE_BLOCKS")) : 512;
+    if (cap == 512) cap = ess_cap;
     int64_t g = (n + kScanBlock - 1) / kScanBlock;
     if (g > cap) g = cap;    // grid-stride the rest
     if (g < 1) g = 1;
@@ -628,7 +655,7 @@ void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const do
     EssCand cand{};
     cand.k = k;
     for (int i = 0; i < SMC_MAX_ESS_CAND; ++i) cand.gm[i] = (i < k) ? gm[i] : 0.0;
-    const int g = reduce_grid(n);
+    const int g = reduce_grid(n, 512);
     int K;
     if (k <= 1) {
         K = 1;
@@ -681,8 +708,14 @@ void launch_mh_transform(smc_ctx *c, const double *d_mom, const double *d_sums, 
                          double *d_cov, double *d_xform) {
     WCov w{};
     for (int i = 0; i < c->dim * c->dim; ++i) w.w[i] = w_cov[i];
-    hipLaunchKernelGGL(mh_transform_kernel, dim3(1), dim3(64), 0, c->stream, d_mom, d_sums, (double)c->n_global, w, c->dim,
-                       d_shift, d_cov, d_xform);
+    const double ng = (double)c->n_global;
+#define SMC_XF(D) case D: hipLaunchKernelGGL((mh_transform_kernel<D>), dim3(1), dim3(64), 0, c->stream, d_mom, d_sums, ng, w, \
+                                             d_shift, d_cov, d_xform); break
+    switch (c->dim) {
+        SMC_XF(1); SMC_XF(2); SMC_XF(3); SMC_XF(4); SMC_XF(5); SMC_XF(6); SMC_XF(7); SMC_XF(8);
+    }
+#undef SMC_XF
+    static_assert(SMC_MAX_DIM == 8, "one instantiation of mh_transform_kernel per dimension");
 }
 // per-block rows of nv doubles (accept kernel) -> out[0..nv), then the sweep's accept counters as doubles (exact below 2^53):
 // out[nv] = accepted_now, out[nv+1] = accepted_ever, out[nv+2] = n_failed - ONE vector for ONE all-reduce per iteration
@@ -690,20 +723,20 @@ __global__ void __launch_bounds__(kScanBlock) moments_reduce_kernel(const double
                                                                     const SweepCounters *__restrict__ counters,
                                                                     double *__restrict__ out) {
     __shared__ double lds[4];
-    for (int v = 0; v < nv; ++v) {
+    const int v = blockIdx.x;          // one block per value, the last block carries the counters
+    if (v < nv) {
         double s = 0.0;
         for (int i = threadIdx.x; i < n_rows; i += blockDim.x) s += rows[(size_t)i * nv + v];
         s = block_sum(s, lds);
         if (threadIdx.x == 0) out[v] = s;
-    }
-    if (threadIdx.x == 0) {
+    } else if (threadIdx.x == 0) {
         out[nv] = (double)counters->accepted_now;
         out[nv + 1] = (double)counters->accepted_ever;
         out[nv + 2] = (double)counters->n_failed;
     }
 }
 void launch_moments_reduce(smc_ctx *c, int n_rows, int nv, double *d_out) {
-    hipLaunchKernelGGL(moments_reduce_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, n_rows, nv, c->d_counters,
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3(nv + 1), dim3(kScanBlock), 0, c->stream, c->d_partials, n_rows, nv, c->d_counters,
                        d_out);
 }
 
