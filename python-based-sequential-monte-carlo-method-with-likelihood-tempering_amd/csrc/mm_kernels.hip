@@ -16,9 +16,11 @@
 //   mm_finish_kernel    per particle: the n_ex sums -> logL in experiment order (:70-73), then
 //                       either store it (likelihood sweep) or accept/select (:231-241).
 //
-// Item order: item = (block64 * n_ex + e) * 64 + l  <->  particle block64*64 + l, experiment e, so
-// consecutive items share the experiment (same LDS rows, broadcast reads) and read consecutive
-// particles (coalesced SoA rows).
+// Item order: item = (e * n_blocks64 + block64) * 64 + l  <->  particle block64*64 + l, experiment e: consecutive
+// items share the experiment (same LDS rows, broadcast reads) and read consecutive particles (coalesced SoA rows), and
+// the experiments of ONE particle lie n_blocks64 groups apart.  Stiffness is a property of the particle (the long solves
+// have Vmax/Km > ~250: ~3.7 Vmax/Km T attempts) that shows in several of its experiments; with the particle-major order
+// of round 1 two of them used to land in one wave, whose tail then could not take the single-item path below.
 //
 // Roofline: FP64 vector ALU (no contraction over a dimension > 7, hence no MFMA); HBM traffic of a
 // whole sweep is ~200 B per particle against ~2e4 flop (DESIGN.md "Kernels").
@@ -106,6 +108,13 @@ struct SolveArgs {
     unsigned long long *queue;  // global item counter (zeroed before the launch)
 };
 
+// value of lane `src` (wave-uniform index) in every lane, as a scalar
+__device__ __forceinline__ double lane_value(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 template <bool WRITE_PRED>
 __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, SolveArgs a) {
     extern __shared__ double smem[];
@@ -121,7 +130,8 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
     __syncthreads();
 
     // items are laid out in groups of 64 particles x n_ex experiments; the last group may be partial
-    const unsigned long long n_items = (unsigned long long)((a.n + kWave - 1) / kWave) * kWave * n_ex;
+    const unsigned long long n_blk = (unsigned long long)((a.n + kWave - 1) / kWave);
+    const unsigned long long n_items = n_blk * kWave * n_ex;
     const int lane = threadIdx.x & (kWave - 1);
     const double rtol = mm.rtol, atol = mm.atol;
 
@@ -164,9 +174,9 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                 handed_out = true;
                 if (!live && my < take) {
                     const unsigned long long item = q_lo + my;
-                    const unsigned long long grp = item >> 6;            // 64-item group
-                    const int e = (int)(grp % (unsigned)n_ex);
-                    const int64_t p = (int64_t)(grp / (unsigned)n_ex) * kWave + (int64_t)(item & 63);
+                    const unsigned long long grp = item >> 6;            // 64-item group = (experiment, block of 64 particles)
+                    const int e = (int)(grp / n_blk);                    // experiment-major: see the item order note above
+                    const int64_t p = (int64_t)(grp % n_blk) * kWave + (int64_t)(item & 63);
                     if (p < a.n) {
                         out_idx = (int64_t)e * a.n + p;
                         bool run = true;
@@ -197,18 +207,70 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
             }
         }
         if (drained) {
-            // tail: no item is left to hand out.  What remains are the long serial chains of stiff items;
-            // run each lane's item to completion in a tight per-lane loop (no ballots, no refill logic).
-            if (live) {
-                int st;
+            // tail: no item is left to hand out.  What remains are the long serial chains of stiff items.
+            // A wave that holds exactly ONE of them (the usual case: they are 1 in 10^3 .. 10^4 items) runs it with the
+            // item's state broadcast to the whole wave through v_readlane: every operand is then wave-uniform, the
+            // compiler turns the accept / reject / output branches into scalar branches and drops the per-lane selects,
+            // and the attempt takes 0.42 instead of 0.52 us (tools/attempt_probe.hip: the same solve with uniform and
+            // with per-lane operands; tools/tail_latency.py on the product kernel).  The arithmetic is the same
+            // function on the same operands, so the result is bit-identical.
+            for (;;) {
+                const unsigned long long tail_mask = __ballot(live);
+                const int n_live = __popcll(tail_mask);
+                if (n_live == 0) break;
+                if (n_live == 1) {
+                    const int src = __ffsll((unsigned long long)tail_mask) - 1;
+                    MMItem u;
+                    u.negVmax = lane_value(it.negVmax, src);
+                    u.Km = lane_value(it.Km, src);
+                    u.S0 = lane_value(it.S0, src);
+                    u.t = lane_value(it.t, src);
+                    u.y = lane_value(it.y, src);
+                    u.f = lane_value(it.f, src);
+                    u.h_abs = lane_value(it.h_abs, src);
+                    u.min_step = lane_value(it.min_step, src);
+                    u.t_bound = lane_value(it.t_bound, src);
+                    u.t_next = lane_value(it.t_next, src);
+                    u.sum_r2 = lane_value(it.sum_r2, src);
+                    u.t_off = __builtin_amdgcn_readlane(it.t_off, src);
+                    u.i_out = __builtin_amdgcn_readlane(it.i_out, src);
+                    u.attempts = __builtin_amdgcn_readlane(it.attempts, src);
+                    u.rejected = __builtin_amdgcn_readlane((int)it.rejected, src) != 0;
+                    double *u_pred = nullptr;
+                    if (WRITE_PRED) {
+                        const unsigned long long pv = (unsigned long long)pred_item;
+                        u_pred = (double *)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(pv >> 32), src) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, src));
+                    }
+                    int st;
+                    do {
+                        st = mm_item_attempt<WRITE_PRED>(u, s_t, s_P, n_t, rtol, atol, u_pred);
+                    } while (st == 0);
+                    if (lane == src) {
+                        const bool ok = (st == 1) && (u.i_out == n_t);
+                        a.sum_r2[out_idx] = ok ? u.sum_r2 : quiet_nan();
+                        a.info[out_idx] = u.attempts | (ok ? 0 : (1 << 30));
+                        if (WRITE_PRED && !ok)
+                            for (int i = u.i_out; i < n_t; ++i) u_pred[i] = quiet_nan();
+                    }
+                    break;
+                }
+                // several stiff items in this wave: per-lane attempts until one of them is done, then look again
+                int n_now;
                 do {
-                    st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
-                } while (st == 0);
-                const bool ok = (st == 1) && (it.i_out == n_t);
-                a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
-                a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
-                if (WRITE_PRED && !ok)
-                    for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
+                    if (live) {
+                        const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
+                        if (st != 0) {
+                            const bool ok = (st == 1) && (it.i_out == n_t);
+                            a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
+                            a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
+                            if (WRITE_PRED && !ok)
+                                for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
+                            live = false;
+                        }
+                    }
+                    n_now = __popcll(__ballot(live));
+                } while (n_now == n_live);
             }
             break;
         }
