@@ -85,3 +85,46 @@ def test_ess_searches_on_degenerate_likelihoods(pkg):
             eng.upload_lk(pkg.SMC_SET_PRED, lk)
             es = pkg.ess_search(eng, pkg.SingleComm(), 0.25, s)
             assert es["warning"] and 0.25 < es["gamma_new"] < 0.25 + 1e-8 and es["ess"] < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 130, 257, 1000, 4097])
+def test_fused_iterations_and_whole_runs_at_odd_population_sizes(pkg, O, data, n):
+    """The fused Metropolis iteration (smc_mh_iteration_device_rng: carried moments, per-block moment rows, the factor
+    kernel) and the on-device reductions of a whole device-RNG run at population sizes around the wave / block / tile
+    boundaries, down to a single particle (cov_m = 0: the proposal is the particle itself and must be accepted).  After
+    every iteration: p_filt differs from its predecessor in exactly accepted_now rows (or fewer when a proposal equals
+    its particle), the flags count accepted_ever, and the next iteration's cov_m is NumPy's covariance of what is there."""
+    s = pkg.SMCSettings(n_particle=n)
+    w_cov = s.w_cov()
+    rs = np.random.RandomState(n)
+    th = np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((n, 3)) * np.array([0.025, 0.0295, 0.00094])
+    with pkg.HipEngine(n, 3, device=0) as eng:
+        eng.set_model_mm(data.t, data.P_obs, data.S0)
+        eng.set_prior(s.priors)
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        eng.loglik(pkg.SMC_SET_PRED)
+        lk_ref = O.mm_loglik_batch(th, data)[0]
+        assert np.max(np.abs(eng.download_lk(pkg.SMC_SET_PRED) - lk_ref) / np.maximum(1.0, np.abs(lk_ref))) < TOL
+        eng.upload_particles(pkg.SMC_SET_FILT, th)
+        eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+        eng.reset_accept_flags()
+        cur = th
+        for j in range(3):
+            out = eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 11, (3 << 16) | j, 0)
+            ref = np.cov(cur.T, bias=True) * w_cov if n > 1 else np.zeros((3, 3))
+            assert np.abs(out["cov_m"] - ref).max() <= 1e-10 * max(np.abs(ref).max(), 1e-300), (j, out["cov_m"], ref)
+            new = eng.download_particles(pkg.SMC_SET_FILT)
+            moved = int(np.any(new != cur, axis=1).sum())
+            assert moved <= out["accepted_now"] <= n and out["n_failed"] == 0
+            if n > 1:
+                assert moved == out["accepted_now"]
+            assert int(eng.download_accept_flags().sum()) == out["accepted_ever"]
+            lk_new = O.mm_loglik_batch(new, data)[0]
+            assert np.max(np.abs(eng.download_lk(pkg.SMC_SET_FILT) - lk_new) / np.maximum(1.0, np.abs(lk_new))) < TOL
+            cur = new
+        if n >= 63:
+            run = pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=n)
+            assert run["gamma"] == 1.0 and all(r["n_offspring"] in (n - 1, n) for r in run["records"])
+            lk_end = O.mm_loglik_batch(run["p_pred"], data)[0]
+            assert np.max(np.abs(run["lk"] - lk_end) / np.maximum(1.0, np.abs(lk_end))) < TOL
