@@ -112,14 +112,20 @@ def cpu_baseline(sample_seconds_target=15.0):
             "ess_iters_per_s_n1e6_1core": 1.0 / dt_e}
 
 
-def kernel_source_sha():
-    """sha256 over the sources libsmc_hip.so is built from: ties a profile (profiles/*pmc*summary.json) to a kernel revision."""
+def kernel_source_sha(root=None):
+    """sha256 over the CODE libsmc_hip.so is built from (comments and white space stripped, so that editing a comment does not
+    pretend to be a new kernel): ties a profile (profiles/*pmc*summary.json) to a kernel revision."""
+    import re
+    root = root or ROOT
     h = hashlib.sha256()
-    csrc = os.path.join(entry.PKG_DIR, "csrc")
+    csrc = os.path.join(root, os.path.basename(entry.PKG_DIR), "csrc")
     for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
-                    [os.path.join(ROOT, "include", "smc_hip.h")]):
+                    [os.path.join(root, "include", "smc_hip.h")]):
+        txt = open(f, encoding="utf-8", errors="replace").read()
+        txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)          # block comments
+        txt = re.sub(r"//[^\n]*", " ", txt)                        # line comments (no string literal of the sources holds //)
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(" ".join(txt.split()).encode())
     return h.hexdigest()[:16]
 
 

@@ -213,11 +213,15 @@ int smc_mh_step_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, cons
                            uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
                            int64_t *n_failed, int64_t *rk_attempts);
 /* One whole Metropolis iteration of the device-RNG mode on the stream (Micmem_SMC_main.py:212-241), every rank calling it
- * together: cov_m = np.cov(p_filt.T, bias=True) * w_cov from device-side moments all-reduced in place (:212-215), the factor
- * NumPy's legacy multivariate_normal multiplies standard normals with - (u,s,v) = svd(cov_m), sqrt(s)[:,None]*v - computed on
- * the device (cov_m is symmetric: a Jacobi eigen-decomposition, |lambda| sorted descending, largest component of each row
- * positive), then proposal, support mask, likelihood, accept/select as in smc_mh_step_device_rng, then the accept counts
- * summed over the ranks.  One synchronisation.  w_cov: d x d (Micmem_settings.py:94-97).  accepted_now, accepted_ever and
+ * together: cov_m = np.cov(p_filt.T, bias=True) * w_cov (:212-215), the factor NumPy's legacy multivariate_normal multiplies
+ * standard normals with - (u,s,v) = svd(cov_m), sqrt(s)[:,None]*v - computed on the device (cov_m is symmetric: a Jacobi
+ * eigen-decomposition, |lambda| sorted descending, largest component of each row positive), then proposal, support mask,
+ * likelihood, accept/select as in smc_mh_step_device_rng, then the accept counts summed over the ranks.  ONE synchronisation.
+ * Moments: the first call after anything else wrote SMC_SET_FILT (upload, resampling, smc_mh_step_*) takes np.cov's own
+ * two-pass route (column sums -> all-reduce -> sums centred about the global mean -> all-reduce); for the Michaelis-Menten
+ * model every later call gets them from the accept kernel of the call before, which accumulates the moments of the
+ * particles it selects about the previous mean - no pass over the particles, and moments + accept counts travel in ONE
+ * all-reduce of d + d(d+1)/2 + 3 doubles.  w_cov: d x d (Micmem_settings.py:94-97).  accepted_now, accepted_ever and
  * n_failed are totals over ALL ranks, rk_attempts_local is this rank's; cov_m (optional, d x d) receives the global cov_m. */
 int smc_mh_iteration_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed,
                                 uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
