@@ -68,3 +68,40 @@ def test_bench_under_torch_distributed_run():
 def test_bench_does_not_import_torch():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "import torch" not in src
+
+
+def test_roofline_traffic_is_tied_to_kernel_revision_and_population(tmp_path, monkeypatch):
+    """roofline.traffic may only come from a PMC profile of the kernel revision and population size being benchmarked
+    (the round-1 bench read a stale file for any --particles-per-gpu)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    k = "void smc::mm_solve_kernel<false>"
+    prof = {"meta": {"kernel_source_sha": bench.kernel_source_sha(), "particles_per_gpu": 1000, "command": "x"},
+            "pmc_fetch": {k: {"avg_counter_value": 10.0}}, "pmc_write": {k: {"avg_counter_value": 5.0}}}
+    (tmp_path / "profiles").mkdir()
+    json.dump(prof, open(tmp_path / "profiles" / "r99_pmc_fetch_write_summary.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda root=None: prof["meta"]["kernel_source_sha"])
+    b, note = bench.measured_traffic(k, 1000)
+    assert b == (2 * 10.0 + 5.0) * 1024 and "r99_pmc" in note
+    assert bench.measured_traffic(k, 2000)[0] is None                       # another population size
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda root=None: "somethingelse")
+    b, note = bench.measured_traffic(k, 1000)
+    assert b is None and "another kernel revision" in note                  # another kernel build
+
+
+def test_kernel_revision_hash_ignores_comments(tmp_path):
+    sys.path.insert(0, ROOT)
+    import bench
+    import shutil
+    pkg = os.path.basename(bench.entry.PKG_DIR)
+    shutil.copytree(os.path.join(ROOT, pkg, "csrc"), tmp_path / pkg / "csrc",
+                    ignore=shutil.ignore_patterns("*.o", "*.so"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    a = bench.kernel_source_sha(str(tmp_path))
+    assert a == bench.kernel_source_sha()
+    f = tmp_path / pkg / "csrc" / "mm_rk45.h"
+    f.write_text("// a new comment\n" + f.read_text() + "\n/* and\n another */\n")
+    assert bench.kernel_source_sha(str(tmp_path)) == a
+    f.write_text(f.read_text().replace("#define A21 (1.0 / 5)", "#define A21 (1.0 / 4)"))
+    assert bench.kernel_source_sha(str(tmp_path)) != a
