@@ -126,6 +126,16 @@ int smc_set_prior_mode(smc_ctx *ctx, int mode);
 #define SMC_RESAMPLE_RESIDUAL_SYSTEMATIC 0
 #define SMC_RESAMPLE_SYSTEMATIC 1
 #define SMC_RESAMPLE_MULTINOMIAL 2
+/* Exact early rejection in the Metropolis sweeps of the Michaelis-Menten model (default: on).  The accept test
+ * exp((lk2-lk1)*gamma)*p0 >= rr (Micmem_SMC_main.py:231-236) has lk1 and rr fixed before the proposal is solved, and lk2 = sum
+ * over the experiments of c0 - sum(residual^2)/(2 sigma^2) only decreases while a solve accumulates residuals.  A solve
+ * whose proposal fails the test even with the sums accumulated SO FAR (0 for experiments still running) is stopped: the
+ * proposal is rejected exactly as the completed computation would reject it - p_filt, lk1, accept flags and counts are
+ * unchanged; only rk_attempts is smaller, a step-size underflow in the skipped part of a solve cannot be reported (the
+ * reference would raise there; none occurs on this model), and the lk2 of such a proposal is never formed (the debug
+ * capture therefore switches the feature off).  It removes the long solves that dominate the early tempering steps:
+ * they are proposals with Vmax/Km in the thousands whose other experiments already rule them out. */
+int smc_set_early_reject(smc_ctx *ctx, int enable);
 int smc_set_resampling(smc_ctx *ctx, int scheme);
 
 /* ---- particle movement -------------------------------------------------------------------- */

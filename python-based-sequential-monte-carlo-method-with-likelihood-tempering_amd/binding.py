@@ -54,6 +54,7 @@ SIGNATURES = {
     "smc_set_prior": (cint, [c_ctx, c_ip, c_dp, c_dp, cint]),
     "smc_set_prior_mode": (cint, [c_ctx, cint]),
     "smc_set_resampling": (cint, [c_ctx, cint]),
+    "smc_set_early_reject": (cint, [c_ctx, cint]),
     "smc_upload_particles": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_download_particles": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_upload_lk": (cint, [c_ctx, cint, c_dp, i64]),

@@ -35,6 +35,12 @@
 
 namespace smc {
 
+// info word of an item: attempts | cancelled << 29 | failed << 30
+constexpr int kInfoAttemptsMask = 0x1fffffff, kInfoCancelled = 1 << 29, kInfoFailed = 1 << 30;
+// sum_r2 of an item as other waves see it DURING a sweep with early rejection: NaN = not finished yet (or failed),
+// kSumCancelled = stopped because its proposal is certainly rejected, >= 0 = finished
+constexpr double kSumCancelled = -1.0;
+
 // ---------------------------------------------------------------------------------------------
 // proposal (Micmem_SMC_main.py:220-228)
 // ---------------------------------------------------------------------------------------------
@@ -48,6 +54,8 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
     }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (mh.pending_sums)   // early rejection reads the siblings' results: none of this sweep's items has finished yet
+        for (int k = 0; k < mh.pending_n_ex; ++k) mh.pending_sums[(int64_t)k * n + p] = __longlong_as_double(0x7ff8000000000000LL);
     const double f0 = filt[p], f1 = filt[stride + p], f2 = filt[2 * stride + p];
     double z0, z1, z2;
     if (mh.device_rng) {
@@ -106,7 +114,73 @@ struct SolveArgs {
     int *info;                  // [e*n + p]: attempts | failed << 30
     double *pred;               // optional: P_model, [(p*n_ex + e)*n_t + i]
     unsigned long long *queue;  // global item counter (zeroed before the launch)
+    // Exact early rejection (Metropolis sweeps only; lk1 == nullptr: off).  See mm_certainly_rejected().
+    const double *lk1;          // likelihood of the current particles (lk1, Micmem_SMC_main.py:231)
+    const double *rr;           // host-RNG mode: the uniforms of :235
+    const double *pratio;       // prior_mode != MASK: p0_2 / p0_1
+    double gamma;
+    uint64_t seed, stream;
+    int64_t global_offset;
+    int device_rng, prior_mode;
 };
+
+// one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
+// both evaluate the same floating-point expression
+__device__ __forceinline__ double mm_loglik_term(double c0, double sum_r2, double s2) { return c0 - sum_r2 / (2.0 * s2); }
+
+// The sum of an item must become visible to waves on other XCDs while the kernel runs (L2 is not coherent across XCDs):
+// ONE relaxed agent-scope 8-byte store (write-through, no fence: a release per item tripled the time of a sweep).  The
+// sum itself says whether the item is finished (see kSumCancelled), so no ordering with the info word is needed; the info
+// word is only read by the accept kernel, after this kernel has ended.
+__device__ __forceinline__ void publish_item(const SolveArgs &a, int64_t idx, double sum_r2, int info) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.sum_r2) + idx, (unsigned long long)__double_as_longlong(sum_r2),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.info[idx] = info;
+}
+
+// EXACT early rejection.  The accept test of the sweep (Micmem_SMC_main.py:231-236) is  exp((lk2 - lk1) * gamma) [* p0_2/p0_1]
+// >= rr  with lk2 = sum over the experiments of c0 - sum_r2_e / (2 sigma^2), and both lk1 and rr are known before the solve
+// (device RNG: the uniform is a pure function of the Philox key).  sum_r2_e only grows while a solve runs, so replacing the
+// sums of the unfinished experiments by what they have accumulated so far (0 for a sibling still running elsewhere) gives
+// an UPPER bound of lk2 - in floating point too, because every operation of the expression is monotone and the bound runs
+// through the same expression in the same order.  If even the bound fails the test, the proposal is rejected whatever the
+// rest of the solve would add: the solve can stop, and nothing observable changes (p_filt, lk1, the accept flags and counts
+// are those of the full computation; only the attempt counters are smaller).  The long solves of a sweep are proposals with
+// Vmax/Km in the thousands; their other experiments finish within microseconds and fit so badly that the bound decides
+// 469 of 470 of them (CPU replay of a 1e6-particle run) before the long solve has produced a single output.
+// Returns true only when rejection is certain; any NaN makes the comparison false.  `cancel_seen`: a sibling was already
+// cancelled, i.e. the particle is known to be rejected.
+__device__ __forceinline__ bool mm_certainly_rejected(const MMModel &mm, const SolveArgs &a, int64_t p, int e_self,
+                                                      double partial_self) {
+    const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
+    if (!(sigma > 0.0)) return false;
+    const double s2 = sigma * sigma;
+    const double c0 = (-0.5 * mm.n_t) * log(2.0 * 3.141592653589793 * s2);
+    double lk2_bound = 0.0;
+    for (int k = 0; k < mm.n_ex; ++k) {
+        double S = 0.0;
+        if (k == e_self) {
+            S = partial_self;
+        } else {
+            const double v = __longlong_as_double((long long)__hip_atomic_load(
+                reinterpret_cast<unsigned long long *>(a.sum_r2) + (int64_t)k * a.n + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (v < 0.0) return true;      // kSumCancelled: a sibling has already established the rejection
+            if (v == v) S = v;             // finished; NaN = still running (or failed): counts as 0
+        }
+        lk2_bound += mm_loglik_term(c0, S, s2);
+    }
+    double rr;
+    if (a.device_rng) {
+        const u32x4 ru = philox_block(a.seed, (uint64_t)(a.global_offset + p), a.stream, SMC_PHILOX_BLOCK_UNIFORM);
+        rr = u01_from(ru.x, ru.y);
+    } else {
+        rr = a.rr[p];
+    }
+    double pp = exp((lk2_bound - a.lk1[p]) * a.gamma);
+    if (a.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * a.pratio[p];
+    return pp < rr * (1.0 - 1e-12);   // the margin covers a last-bit non-monotonicity of exp
+}
+constexpr int kRejectCheckEvery = 512;   // attempts between two looks at the bound (a look costs about five attempts)
 
 // value of lane `src` (wave-uniform index) in every lane, as a scalar
 __device__ __forceinline__ double lane_value(double v, int src) {
@@ -190,12 +264,10 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                                                              pred_item);
                             if (!live) {  // nothing to integrate: finished at once
                                 const bool ok = (it.i_out == n_t);
-                                a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
-                                a.info[out_idx] = ok ? 0 : (1 << 30);
+                                publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), ok ? 0 : kInfoFailed);
                             }
                         } else {
-                            a.sum_r2[out_idx] = 0.0;
-                            a.info[out_idx] = 0;
+                            publish_item(a, out_idx, 0.0, 0);
                             if (WRITE_PRED) {
                                 double *pp = a.pred + ((size_t)p * n_ex + e) * n_t;
                                 for (int i = 0; i < n_t; ++i) pp[i] = quiet_nan();
@@ -242,28 +314,52 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                         u_pred = (double *)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(pv >> 32), src) << 32) |
                                             (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, src));
                     }
-                    int st;
+                    const int64_t u_idx = ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(out_idx >> 32), src) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)out_idx, src);
+                    const int u_e = (int)(u_idx / a.n);
+                    const int64_t u_p = u_idx - (int64_t)u_e * a.n;
+                    int st = 0, next_check = u.attempts;          // first look at the bound at once
+                    bool cancelled = false;
                     do {
+                        if (a.lk1 && u.attempts >= next_check) {
+                            if (mm_certainly_rejected(mm, a, u_p, u_e, u.sum_r2)) {
+                                cancelled = true;
+                                break;
+                            }
+                            next_check = u.attempts + kRejectCheckEvery;
+                        }
                         st = mm_item_attempt<WRITE_PRED>(u, s_t, s_P, n_t, rtol, atol, u_pred);
                     } while (st == 0);
                     if (lane == src) {
-                        const bool ok = (st == 1) && (u.i_out == n_t);
-                        a.sum_r2[out_idx] = ok ? u.sum_r2 : quiet_nan();
-                        a.info[out_idx] = u.attempts | (ok ? 0 : (1 << 30));
-                        if (WRITE_PRED && !ok)
-                            for (int i = u.i_out; i < n_t; ++i) u_pred[i] = quiet_nan();
+                        if (cancelled) {
+                            publish_item(a, out_idx, kSumCancelled, u.attempts | kInfoCancelled);
+                        } else {
+                            const bool ok = (st == 1) && (u.i_out == n_t);
+                            publish_item(a, out_idx, ok ? u.sum_r2 : quiet_nan(), u.attempts | (ok ? 0 : kInfoFailed));
+                            if (WRITE_PRED && !ok)
+                                for (int i = u.i_out; i < n_t; ++i) u_pred[i] = quiet_nan();
+                        }
                     }
                     break;
                 }
                 // several stiff items in this wave: per-lane attempts until one of them is done, then look again
-                int n_now;
+                int n_now, since_check = kRejectCheckEvery;     // first look at the bound at once
                 do {
+                    if (live) {
+                        if (a.lk1 && ++since_check > kRejectCheckEvery) {
+                            since_check = 0;
+                            const int e_self = (int)(out_idx / a.n);
+                            if (mm_certainly_rejected(mm, a, out_idx - (int64_t)e_self * a.n, e_self, it.sum_r2)) {
+                                publish_item(a, out_idx, kSumCancelled, it.attempts | kInfoCancelled);
+                                live = false;
+                            }
+                        }
+                    }
                     if (live) {
                         const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
                         if (st != 0) {
                             const bool ok = (st == 1) && (it.i_out == n_t);
-                            a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
-                            a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
+                            publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), it.attempts | (ok ? 0 : kInfoFailed));
                             if (WRITE_PRED && !ok)
                                 for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
                             live = false;
@@ -284,8 +380,7 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                 const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
                 if (st != 0) {
                     const bool ok = (st == 1) && (it.i_out == n_t);
-                    a.sum_r2[out_idx] = ok ? it.sum_r2 : quiet_nan();
-                    a.info[out_idx] = it.attempts | (ok ? 0 : (1 << 30));
+                    publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), it.attempts | (ok ? 0 : kInfoFailed));
                     if (WRITE_PRED && !ok)
                         for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
                     live = false;
@@ -323,6 +418,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
         const int n_ex = mm.n_ex;
         const double sigma = mm.est_sigma ? theta[2 * stride + p] : mm.sigma_fixed;
         const bool masked = (MODE == 1) && (p0_in[p] == 0);
+        bool cancelled = false;   // a solve of this proposal stopped because its rejection was certain (mm_certainly_rejected)
         double lk2;
         if (masked) {
             lk2 = lk_io[p];  // proposal was reset to the current point: the likelihood is the stored one
@@ -334,10 +430,11 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
             lk2 = 0.0;
             unsigned pf = 0;
             for (int k = 0; k < n_ex; ++k) {
-                lk2 += c0 - sum_r2[(int64_t)k * n + p] / (2.0 * s2);                // :70-73
+                lk2 += mm_loglik_term(c0, sum_r2[(int64_t)k * n + p], s2);          // :70-73
                 const int fl = info[(int64_t)k * n + p];
-                attempts += (unsigned)(fl & 0x3fffffff);
+                attempts += (unsigned)(fl & kInfoAttemptsMask);
                 pf |= (unsigned)(fl >> 30) & 1u;
+                cancelled = cancelled || (fl & kInfoCancelled) != 0;
             }
             failed += pf;
         }
@@ -346,6 +443,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
         } else {
             // ---- accept / select (:231-241) ----
             const double lk1 = lk_io[p];
+            if (cancelled) lk2 = lk1;   // rejected for certain: its logL was never completed and is not needed (r = 0 below)
             const double p0 = masked ? 0.0 : 1.0;
             double rr;
             if (mh.device_rng) {
@@ -359,7 +457,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
             double pp = exp(px * mh.gamma);
             if (mh.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * mh.pratio[p];
             if (mh.prior_mode != SMC_PRIOR_MODE_RATIO) pp = pp * p0;
-            const double r = (pp >= rr) ? 1.0 : 0.0;
+            const double r = (!cancelled && pp >= rr) ? 1.0 : 0.0;
             const double nr = 1.0 - r;
             double sel[3];
             for (int c = 0; c < 3; ++c) {
@@ -429,7 +527,7 @@ static unsigned finish_grid(int64_t n) {
 }
 
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
-                         bool queue_cleared = false) {
+                         bool queue_cleared = false, const MHParams *mh_reject = nullptr) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
     a.theta = theta;
@@ -440,6 +538,17 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.info = ctx->d_info;
     a.pred = pred;
     a.queue = ctx->d_queue;
+    if (mh_reject) {
+        a.lk1 = ctx->set[SMC_SET_FILT].lk;
+        a.rr = mh_reject->rr;
+        a.pratio = mh_reject->pratio;
+        a.gamma = mh_reject->gamma;
+        a.seed = mh_reject->seed;
+        a.stream = mh_reject->stream;
+        a.global_offset = mh_reject->global_offset;
+        a.device_rng = mh_reject->device_rng;
+        a.prior_mode = mh_reject->prior_mode;
+    }
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = (size_t)(2 * mm.n_ex * mm.n_t + mm.n_ex) * sizeof(double);
     // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more blocks than chunks
@@ -464,14 +573,21 @@ void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t
                        nullptr, nullptr);
 }
 
-void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
+void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     if (n <= 0) return;
     ParticleSet &F = ctx->set[SMC_SET_FILT];
     ParticleSet &P = ctx->set[SMC_SET_PRED];  // receives the proposals, as the reference's p_pred does (:220,228)
     const bool dbg = ctx->debug_capture != 0;
+    // exact early rejection: off while the proposals' likelihoods are captured for inspection (they would be incomplete)
+    const bool reject = ctx->early_reject != 0 && !dbg && mh_in.gamma > 0.0;
+    MHParams mh = mh_in;
+    if (reject) {
+        mh.pending_sums = ctx->d_sum_r2;
+        mh.pending_n_ex = ctx->mm.n_ex;
+    }
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
-    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.zero_queue != nullptr);
+    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.zero_queue != nullptr, reject ? &mh : nullptr);
     ctx->moment_rows_n = mh.moment_rows ? (int)finish_grid(n) : 0;
     hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        P.theta, P.stride, n, ctx->d_sum_r2, ctx->d_info, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac,

@@ -365,6 +365,12 @@ int smc_meth_download_solves(smc_ctx *c, double *flows, int32_t *status, int64_t
     return 0;
 }
 
+int smc_set_early_reject(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    c->early_reject = enable != 0;
+    return 0;
+}
+
 int smc_set_resampling(smc_ctx *c, int scheme) {
     if (!c) return fail(nullptr, "NULL context");
     if (scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC && scheme != SMC_RESAMPLE_SYSTEMATIC && scheme != SMC_RESAMPLE_MULTINOMIAL)

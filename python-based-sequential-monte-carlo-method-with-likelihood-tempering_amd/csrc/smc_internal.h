@@ -64,6 +64,9 @@ struct MHParams {    // passed by value to the fused MH kernel
     // ... and the propose kernel clears the sweep counters and the work queue (saves two memset launches per iteration)
     SweepCounters *zero_counters;
     unsigned long long *zero_queue;
+    // ... and, with early rejection on, marks every item of the sweep as not finished yet
+    double *pending_sums;
+    int pending_n_ex;
     uint64_t seed, stream;
     int64_t global_offset;
     int device_rng;
@@ -137,6 +140,7 @@ struct smc_ctx {
     double *d_pratio = nullptr;      // prior density ratio of the proposals (allocated on first use)
     int prior_mode = 0;
     int resampling = 0;              // SMC_RESAMPLE_*
+    int early_reject = 1;            // stop a solve whose proposal is certainly rejected (mm_kernels.hip: mm_certainly_rejected)
     double *d_mn_thr = nullptr;      // multinomial resampling: n_global + 1 thresholds
     double *d_mn_blk = nullptr;      // ... and their per-tile sums
     unsigned long long *d_queue = nullptr;

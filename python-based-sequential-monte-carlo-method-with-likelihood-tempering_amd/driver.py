@@ -59,6 +59,7 @@ class SMCSettings:
     resampling: str = "residual_systematic"   # | "systematic"  (HipEngine.set_resampling; the reference has only the first)
     ess_search: str = "backoff"       # the reference's geometric back-off (main:111-144) | "bisection"
     ess_bisect_tol: float = 1e-9      # bisection: bracket width in gamma at which the search stops
+    early_reject: bool = True         # stop a solve once its proposal is certainly rejected (exact; HipEngine.set_early_reject)
     priors: dict = field(default_factory=lambda: {
         "Vmax": {"dist": "uniform", "low": 0, "high": 10},
         "Km": {"dist": "uniform", "low": 0, "high": 10},
@@ -288,6 +289,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     w_cov = s.w_cov()
     engine.set_prior_mode(s.prior_mode)
     engine.set_resampling(s.resampling)
+    if hasattr(engine, "set_early_reject"):
+        engine.set_early_reject(s.early_reject)
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "particle_mutation_steps": 0}

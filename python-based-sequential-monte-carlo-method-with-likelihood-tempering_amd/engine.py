@@ -173,6 +173,10 @@ class HipEngine:
         m = B.PRIOR_MODES[mode] if isinstance(mode, str) else int(mode)
         self._ck(self.L.smc_set_prior_mode(self.ctx, m), "smc_set_prior_mode")
 
+    def set_early_reject(self, enable=True):
+        """Stop a Michaelis-Menten solve once its proposal is certainly rejected (include/smc_hip.h: smc_set_early_reject)."""
+        self._ck(self.L.smc_set_early_reject(self.ctx, int(bool(enable))), "smc_set_early_reject")
+
     def set_resampling(self, scheme):
         """"residual_systematic" (default, Micmem_SMC_main.py:147-184) or "systematic"."""
         k = B.RESAMPLING[scheme] if isinstance(scheme, str) else int(scheme)

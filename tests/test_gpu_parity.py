@@ -773,8 +773,10 @@ def test_fused_mh_iteration_equals_its_parts(pkg, data, force_rccl, monkeypatch)
     assert np.abs(a["xf"].T @ a["xf"] - a["out"]["cov_m"]).max() <= 1e-13 * np.abs(cov_np).max()
     assert np.abs(_row_signs(a["xf"]) - _row_signs(ref)).max() <= 1e-10 * np.abs(ref).max()
     assert np.array_equal(_row_signs(a["xf"]), a["xf"])           # the kernel's own sign convention
-    for k in ("accepted_now", "accepted_ever", "n_failed", "rk_attempts"):
+    for k in ("accepted_now", "accepted_ever", "n_failed"):
         assert a["out"][k] == b["out"][k], k
+    # (rk_attempts: with early rejection on, where a certainly-rejected solve stops depends on when its siblings finished)
+    assert abs(a["out"]["rk_attempts"] - b["out"]["rk_attempts"]) <= 0.01 * b["out"]["rk_attempts"]
     assert 0 < a["out"]["accepted_now"] < n
     assert np.array_equal(a["filt"], b["filt"]) and np.array_equal(a["lk"], b["lk"]) and np.array_equal(a["flags"], b["flags"])
 
@@ -1022,3 +1024,46 @@ def test_pseudo_data_generator_reproduces_reference_csvs(pkg, data, tmp_path):
         assert np.abs(df["P_obs"].values - data.P_obs[i]).max() < 1e-9
         assert df["S_true"].iloc[0] == data.S0[i]
         assert (tmp_path / f"mm_pseudo_data_{i}.csv").exists()
+
+
+# ---------------------------------------------------------------------------------------------------
+# exact early rejection (smc_set_early_reject): nothing observable may change
+# ---------------------------------------------------------------------------------------------------
+def test_early_rejection_changes_nothing_but_the_attempt_count(pkg, O, data):
+    """A Metropolis iteration on a prior-like population (where the long solves live) with and without early rejection,
+    host-RNG mode against the oracle's decisions, and a complete device-RNG run: p_filt, lk1, accept flags, accept counts,
+    the tempering schedule and the evidence must be bit-identical; only rk_attempts may (and must) shrink."""
+    n = 60000
+    s = pkg.SMCSettings(n_particle=n)
+    rs = np.random.RandomState(3)
+    th = rs.uniform(0, 10, (n, 3))
+    th[: n // 50, 1] = 10.0 ** rs.uniform(-3.3, -2, n // 50)          # stiff band: Vmax / Km in the thousands
+    noise = rs.standard_normal((n, 3)) * np.array([0.5, 0.002, 0.5])
+    rr = rs.uniform(0, 1, n)
+    lk_ref = O.mm_loglik_batch(th, data)[0]
+    res = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            eng.set_early_reject(on)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, lk_ref)
+            out = eng.mh_step_host_rng(0.004, 1.0, noise, rr)
+            res[on] = (out, eng.download_particles(pkg.SMC_SET_FILT), eng.download_lk(pkg.SMC_SET_FILT),
+                       eng.download_accept_flags())
+    a, b = res[True], res[False]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert a[0]["accepted_now"] == b[0]["accepted_now"] and a[0]["accepted_ever"] == b[0]["accepted_ever"]
+    assert a[0]["n_failed"] == b[0]["n_failed"] == 0
+    assert a[0]["rk_attempts"] < 0.95 * b[0]["rk_attempts"], (a[0]["rk_attempts"], b[0]["rk_attempts"])
+    # ... and both equal the reference's statements evaluated by the oracle
+    p_pred, p0, lk2, r, f_ref, l_ref = _mh_reference(O, data, s.priors, th, lk_ref, noise, rr, 0.004, 1.0)
+    assert np.array_equal(a[1], f_ref) and a[0]["accepted_now"] == int(r.sum())
+    runs = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            runs[on] = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n, early_reject=on), rng="device", verbose=False, seed_device=17)
+    a, b = runs[True], runs[False]
+    assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
+    assert [r_["n_accept"] for r_ in a["records"]] == [r_["n_accept"] for r_ in b["records"]]
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+    assert a["stats"]["rk_attempts_mh"] < b["stats"]["rk_attempts_mh"]
