@@ -38,12 +38,16 @@ __device__ __forceinline__ double wave_uniform(double v) {
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-// Next index of a work counter shared by all waves, as a scalar: lane 0 performs the atomic, the join is full-wave.
-// `split` is set when the wave is NOT complete at the join (never, unless the compiler splits the wave again; the host
-// fails the sweep on it).
-__device__ __forceinline__ long long wave_dequeue(unsigned long long *counter, int lane, unsigned &split) {
-    unsigned long long nxt = 0;
-    if (lane == 0) nxt = atomicAdd(counter, 1ULL);
+// Next index of a work counter shared by all waves, as a scalar.  EVERY lane issues the atomic (lane 0 adds `step`, the others
+// add 0; the compiler's atomic optimiser turns that into one wave reduction and one memory atomic) and v_readfirstlane
+// takes lane 0's return value: there is NO divergent branch between the atomic and the cross-lane read.  The obvious
+// `if (lane == 0) nxt = atomicAdd(...); idx = readfirstlane(nxt);` is not safe: HIP guarantees no re-convergence after the
+// `if`, and the compiler is free to run the lanes that skipped it ahead on their own - readfirstlane then returns THEIR
+// nxt = 0.  That is how the round-1 K8 dequeue loop hung, and how the first version of mm_tail_kernel hung in round 2
+// (profiles/r02_k8_dequeue_hang_isa.md, both listings).  `split` is set when the wave is incomplete here anyway.
+__device__ __forceinline__ long long wave_dequeue(unsigned long long *counter, int lane, unsigned &split,
+                                                  unsigned long long step = 1ULL) {
+    const unsigned long long nxt = atomicAdd(counter, lane == 0 ? step : 0ULL);
     split |= (unsigned)(__builtin_amdgcn_read_exec() != ~0ull);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nxt);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nxt >> 32));

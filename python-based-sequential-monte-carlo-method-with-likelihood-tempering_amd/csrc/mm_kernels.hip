@@ -104,6 +104,7 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
 // ---------------------------------------------------------------------------------------------
 constexpr int kSolveBlock = 256;   // 4 waves
 constexpr int kChunk = 128;        // items per global dequeue (2 per lane)
+static_assert(kChunk % 64 == 0, "the chunk dequeue adds kChunk / 64 per lane");
 constexpr int kRefillAt = 16;      // refill a wave once this many lanes are idle (or none is live)
 
 struct SolveArgs {
@@ -228,12 +229,16 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
         bool handed_out = false;
         if (!drained && n_idle >= kRefillAt) {
             if (q_lo == q_hi) {  // next chunk: one atomic per wave and kChunk items
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(a.queue, (unsigned long long)kChunk);
+                // No `if (lane == 0)` around the atomic: the compiler may split such a branch from the v_readfirstlane
+                // that follows it and let the other lanes run ahead with b = 0 (profiles/r02_k8_dequeue_hang_isa.md has
+                // two cases).  Every lane adds kChunk / 64, a wave-uniform operand, so the atomic optimiser issues one
+                // memory atomic of popcount x value and the first lane's return value is the start of the chunk.
+                const unsigned long long b = atomicAdd(a.queue, (unsigned long long)(kChunk / kWave));
                 const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
                 const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
                 q_lo = ((unsigned long long)b_hi << 32) | b_lo;
-                q_hi = (q_lo + kChunk < n_items) ? q_lo + kChunk : n_items;
+                const unsigned long long got = (unsigned long long)__popcll(__builtin_amdgcn_read_exec()) * (kChunk / kWave);
+                q_hi = (q_lo + got < n_items) ? q_lo + got : n_items;
                 if (q_lo >= n_items) {
                     drained = true;
                     q_lo = q_hi = 0;
@@ -318,18 +323,22 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                                           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)out_idx, src);
                     const int u_e = (int)(u_idx / a.n);
                     const int64_t u_p = u_idx - (int64_t)u_e * a.n;
-                    int st = 0, next_check = u.attempts;          // first look at the bound at once
+                    // The look at the bound sits in an outer loop so that the attempt loop itself stays the bare serial
+                    // chain: with the check inside it the compiler kept the check's operands live across every attempt
+                    // and reloaded spilled SGPRs in the loop (0.51 instead of 0.41 us per attempt, tools/tail_latency.py).
+                    int st = 0;
                     bool cancelled = false;
-                    do {
-                        if (a.lk1 && u.attempts >= next_check) {
-                            if (mm_certainly_rejected(mm, a, u_p, u_e, u.sum_r2)) {
-                                cancelled = true;
-                                break;
-                            }
-                            next_check = u.attempts + kRejectCheckEvery;
+                    for (;;) {
+                        if (a.lk1 && mm_certainly_rejected(mm, a, u_p, u_e, u.sum_r2)) {   // first look at once
+                            cancelled = true;
+                            break;
                         }
-                        st = mm_item_attempt<WRITE_PRED>(u, s_t, s_P, n_t, rtol, atol, u_pred);
-                    } while (st == 0);
+                        int budget = kRejectCheckEvery;
+                        do {
+                            st = mm_item_attempt<WRITE_PRED>(u, s_t, s_P, n_t, rtol, atol, u_pred);
+                        } while (st == 0 && --budget > 0);
+                        if (st != 0) break;
+                    }
                     if (lane == src) {
                         if (cancelled) {
                             publish_item(a, out_idx, kSumCancelled, u.attempts | kInfoCancelled);
