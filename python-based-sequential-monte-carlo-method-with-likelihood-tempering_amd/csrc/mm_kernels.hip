@@ -105,7 +105,10 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
 constexpr int kSolveBlock = 256;   // 4 waves
 constexpr int kChunk = 128;        // items per global dequeue (2 per lane)
 static_assert(kChunk % 64 == 0, "the chunk dequeue adds kChunk / 64 per lane");
-constexpr int kRefillAt = 16;      // refill a wave once this many lanes are idle (or none is live)
+#ifndef SMC_REFILL_AT
+#define SMC_REFILL_AT 24
+#endif
+constexpr int kRefillAt = SMC_REFILL_AT;      // refill a wave once this many lanes are idle (or none is live)
 
 struct SolveArgs {
     const double *theta;        // SoA rows: Vmax at [p], Km at [stride + p], sigma at [2*stride + p]
@@ -192,15 +195,11 @@ __device__ __forceinline__ double lane_value(double v, int src) {
 
 template <bool WRITE_PRED>
 __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, SolveArgs a) {
-    extern __shared__ double smem[];
+    extern __shared__ double2 smem_tp[];
     const int n_ex = mm.n_ex, n_t = mm.n_t;
-    double *s_t = smem;              // n_ex*n_t
-    double *s_P = s_t + n_ex * n_t;  // n_ex*n_t
-    double *s_S0 = s_P + n_ex * n_t; // n_ex
-    for (int i = threadIdx.x; i < n_ex * n_t; i += blockDim.x) {
-        s_t[i] = mm.t[i];
-        s_P[i] = mm.P_obs[i];
-    }
+    double2 *s_tp = smem_tp;                                        // n_ex rows of n_t + 1 (time, P_obs) pairs, mm_rk45.h
+    double *s_S0 = reinterpret_cast<double *>(s_tp + n_ex * (n_t + 1));   // n_ex
+    mm_table_fill(s_tp, mm.t, mm.P_obs, n_ex, n_t, threadIdx.x, blockDim.x);
     if (threadIdx.x < n_ex) s_S0[threadIdx.x] = mm.S0[threadIdx.x];
     __syncthreads();
 
@@ -221,6 +220,9 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
     // bookkeeping: 0.19 us per iteration on top of the 0.41 us of an attempt for a wave that runs alone (the stragglers of
     // the early tempering steps), measured with tools/tail_latency.py.
     unsigned long long q_lo = 0, q_hi = 0;  // the wave's current chunk
+    unsigned long long q_grp = 0;           // 64-item group of the chunk's first item, and that group's ...
+    unsigned long long q_blk = 0;           // ... block of 64 particles
+    int q_e = 0;                            // ... and experiment (one 64-bit division per chunk, none per hand-out)
     bool drained = false;                   // the global queue is empty
 
     for (;;) {
@@ -243,6 +245,9 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                     drained = true;
                     q_lo = q_hi = 0;
                 }
+                q_grp = q_lo >> 6;
+                q_e = (int)(q_grp / n_blk);          // experiment-major: see the item order note above
+                q_blk = q_grp - (unsigned long long)q_e * n_blk;
             }
             if (!drained) {
                 const unsigned long long idle_mask = ~live_mask;
@@ -253,9 +258,12 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                 handed_out = true;
                 if (!live && my < take) {
                     const unsigned long long item = q_lo + my;
-                    const unsigned long long grp = item >> 6;            // 64-item group = (experiment, block of 64 particles)
-                    const int e = (int)(grp / n_blk);                    // experiment-major: see the item order note above
-                    const int64_t p = (int64_t)(grp % n_blk) * kWave + (int64_t)(item & 63);
+                    // 64-item group = (experiment, block of 64 particles); a chunk spans at most three groups
+                    unsigned long long blk = q_blk + ((item >> 6) - q_grp);
+                    int e = q_e;
+                    if (blk >= n_blk) { blk -= n_blk; ++e; }
+                    if (blk >= n_blk) { blk -= n_blk; ++e; }
+                    const int64_t p = (int64_t)blk * kWave + (int64_t)(item & 63);
                     if (p < a.n) {
                         out_idx = (int64_t)e * a.n + p;
                         bool run = true;
@@ -265,7 +273,7 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                         if (sigma <= 0.0) run = false;                   // -inf without solving (:53-54)
                         if (run) {
                             if (WRITE_PRED) pred_item = a.pred + ((size_t)p * n_ex + e) * n_t;
-                            live = mm_item_begin<WRITE_PRED>(it, Vmax, Km, s_S0[e], s_t, s_P, e * n_t, n_t, rtol, atol,
+                            live = mm_item_begin<WRITE_PRED>(it, Vmax, Km, s_S0[e], s_tp, mm_table_row(e, n_t), n_t, rtol, atol,
                                                              pred_item);
                             if (!live) {  // nothing to integrate: finished at once
                                 const bool ok = (it.i_out == n_t);
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                         }
                         int budget = kRejectCheckEvery;
                         do {
-                            st = mm_item_attempt<WRITE_PRED>(u, s_t, s_P, n_t, rtol, atol, u_pred);
+                            st = mm_item_attempt<WRITE_PRED>(u, s_tp, n_t, rtol, atol, u_pred);
                         } while (st == 0 && --budget > 0);
                         if (st != 0) break;
                     }
@@ -365,7 +373,7 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
                         }
                     }
                     if (live) {
-                        const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
+                        const int st = mm_item_attempt<WRITE_PRED>(it, s_tp, n_t, rtol, atol, pred_item);
                         if (st != 0) {
                             const bool ok = (st == 1) && (it.i_out == n_t);
                             publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), it.attempts | (ok ? 0 : kInfoFailed));
@@ -386,7 +394,7 @@ __global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, Solve
         int idle_now;
         do {
             if (live) {
-                const int st = mm_item_attempt<WRITE_PRED>(it, s_t, s_P, n_t, rtol, atol, pred_item);
+                const int st = mm_item_attempt<WRITE_PRED>(it, s_tp, n_t, rtol, atol, pred_item);
                 if (st != 0) {
                     const bool ok = (st == 1) && (it.i_out == n_t);
                     publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), it.attempts | (ok ? 0 : kInfoFailed));
@@ -559,7 +567,17 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
         a.prior_mode = mh_reject->prior_mode;
     }
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
-    const size_t lds = (size_t)(2 * mm.n_ex * mm.n_t + mm.n_ex) * sizeof(double);
+    const size_t lds = (size_t)mm.n_ex * (mm.n_t + 1) * sizeof(double2) + (size_t)mm.n_ex * sizeof(double);
+    if (lds > 48 * 1024) {   // the largest data set (16 x 256) needs 66 KB of the CU's 160 KB: above the default dynamic limit
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            raised = true;
+        }
+    }
     // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more blocks than chunks
     const int64_t chunks = (((n + kWave - 1) / kWave) * kWave * mm.n_ex + kChunk - 1) / kChunk;
     int64_t blocks = (int64_t)ctx->cu_count * ctx->solve_blocks_per_cu;

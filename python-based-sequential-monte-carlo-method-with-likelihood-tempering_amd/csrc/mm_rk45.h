@@ -151,26 +151,39 @@ struct MMItem {
     double t_bound;
     double t_next;            // s_t[t_off + i_out], or +inf when every data time has been served
     double sum_r2;            // running sum of squared residuals
-    int t_off;                // offset of the experiment's row in the LDS tables
+    int t_off;                // offset of the experiment's row in the LDS table (mm_table_row)
     int i_out;                // next data time to be served (ivp.py: t_eval_i)
     int attempts;
     bool rejected;            // a rejection happened in the current step (rk.py:131,171)
 };
+
+// The data of the experiments in LDS: one row of n_t + 1 (time, P_obs) pairs per experiment, the last pair being the
+// sentinel (+inf, 0).  The dense-output loop fetches the next time and its observation with ONE ds_read_b128 and needs
+// no test for the end of the row: in the posterior phase a third of the solve kernel's vector instructions are that loop
+// (PMC counts), executed under a partial exec mask.
+__device__ __forceinline__ int mm_table_row(int e, int n_t) { return e * (n_t + 1); }
+__device__ __forceinline__ void mm_table_fill(double2 *s_tp, const double *t, const double *P_obs, int n_ex, int n_t, int tid,
+                                              int n_threads) {
+    for (int i = tid; i < n_ex * (n_t + 1); i += n_threads) {
+        const int e = i / (n_t + 1), k = i - e * (n_t + 1);
+        s_tp[i] = (k < n_t) ? make_double2(t[e * n_t + k], P_obs[e * n_t + k])
+                            : make_double2(__longlong_as_double(0x7ff0000000000000LL), 0.0);
+    }
+}
 
 // Start an item: RungeKutta.__init__ (rk.py:96-104) incl. select_initial_step (common.py:68-134,
 // direction +1, order 4, max_step inf) and the head of the first _step_impl (rk.py:120-127).
 // Returns false when there is nothing to integrate (t0 == t_bound, base.py:181-187): all outputs
 // are then already accumulated.
 template <bool WRITE_PRED>
-__device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km, double S0, const double *s_t,
-                                              const double *s_P, int t_off, int n_t, double rtol, double atol,
-                                              double *pred) {
+__device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km, double S0, const double2 *s_tp,
+                                              int t_off, int n_t, double rtol, double atol, double *pred) {
     it.negVmax = -Vmax;
     it.Km = Km;
     it.S0 = S0;
     it.t_off = t_off;
-    const double t0 = s_t[t_off];
-    it.t_bound = s_t[t_off + n_t - 1];
+    const double t0 = s_tp[t_off].x;
+    it.t_bound = s_tp[t_off + n_t - 1].x;
     it.t = t0;
     it.y = S0;
     it.f = mm_rhs(S0, it.negVmax, Km);
@@ -197,16 +210,16 @@ __device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km
         it.h_abs = py_min(py_min(100.0 * h0, h1), interval);
     }
     if (it.t == it.t_bound) {  // every t_eval <= t gets y
-        while (it.i_out < n_t && s_t[t_off + it.i_out] <= it.t) {
+        while (it.i_out < n_t && s_tp[t_off + it.i_out].x <= it.t) {
             const double P_model = S0 - it.y;
             if (WRITE_PRED) pred[it.i_out] = P_model;
-            const double r = s_P[t_off + it.i_out] - P_model;
+            const double r = s_tp[t_off + it.i_out].y - P_model;
             it.sum_r2 += r * r;
             ++it.i_out;
         }
         return false;
     }
-    it.t_next = s_t[t_off];
+    it.t_next = t0;
     it.min_step = min_step_of(it.t);
     if (it.h_abs < it.min_step) it.h_abs = it.min_step;  // rk.py:122-127 (max_step = inf)
     return true;
@@ -235,11 +248,40 @@ __device__ __forceinline__ RkStages rk_attempt_core(double y, double k0, double 
     return s;
 }
 
+// The outputs with t_eval in (t_old, t_new] of an accepted step (ivp.py:700-720, rk.py:561-574): quartic interpolant,
+// residual against the observation, running sum.  LEAN_X: see the caller.
+template <bool WRITE_PRED, bool LEAN_X>
+__device__ __forceinline__ void mm_dense_outputs(MMItem &it, const double2 *s_tp, double t_old, double t_new, double hd,
+                                                 double y_old, double Q0, double Q1, double Q2, double Q3, double *pred) {
+    int i_out = it.i_out;
+    const int base = it.t_off;
+    double t_next = it.t_next;
+    double sum_r2 = it.sum_r2;
+    double P_obs = s_tp[base + i_out].y;
+    do {
+        const double num = t_next - t_old;
+        const double x = LEAN_X ? lean_div6(num, hd) : num / hd;
+        const double p2 = x * x, p3 = p2 * x, p4 = p3 * x;  // cumprod
+        const double S = hd * (Q0 * x + Q1 * p2 + Q2 * p3 + Q3 * p4) + y_old;
+        const double P_model = it.S0 - S;
+        if (WRITE_PRED) pred[i_out] = P_model;
+        const double r = P_obs - P_model;
+        sum_r2 += r * r;
+        ++i_out;
+        const double2 nx = s_tp[base + i_out];   // i_out == n_t reads the sentinel (+inf, 0)
+        t_next = nx.x;
+        P_obs = nx.y;
+    } while (t_next <= t_new);
+    it.sum_r2 = sum_r2;
+    it.i_out = i_out;
+    it.t_next = t_next;
+}
+
 // One step attempt.  Returns 0 while the item is still running, 1 when it finished (t reached
 // t_bound), 2 when it failed (step size underflow, rk.py:133-134; SciPy status -1).
 template <bool WRITE_PRED, int DIV = kDivLean6>
-__device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, const double *s_P, int n_t, double rtol,
-                                               double atol, double *pred) {
+__device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, int n_t, double rtol, double atol,
+                                               double *pred) {
     // rk.py:133-134 TOO_SMALL_STEP (plus the hard attempt bound): tested together with the other rare
     // conditions in the single branch below; the stages computed meanwhile are simply discarded
     const bool fail = it.h_abs < it.min_step || it.attempts >= RK_MAX_ATTEMPTS;
@@ -273,9 +315,6 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, co
             // ---- outputs with t_eval in (t_old, t] (ivp.py:700-720) by the quartic interpolant ----
             const double k1 = st.k1, k2 = st.k2, k3 = st.k3, k4 = st.k4, k5 = st.k5, k6 = st.k6;
             (void)k1;
-            int i_out = it.i_out;
-        const int base = it.t_off;
-        double t_next = it.t_next;
         // Q = K.T.dot(P) (rk.py:179); P[1][:] = 0 and P[j][0] = 0 for j > 0
         const double Q0 = k0;
         const double Q1 = k0 * (-8048581381.0 / 2820520608) + k2 * (131558114200.0 / 32700410799) +
@@ -288,21 +327,16 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double *s_t, co
                           k3 * (-10690763975.0 / 1880347072) + k4 * (701980252875.0 / 199316789632) +
                           k5 * (-1453857185.0 / 822651844) + k6 * (69997945.0 / 29380423);
         const double hd = t_new - t_old;  // RkDenseOutput.__init__ (rk.py:555)
-        double sum_r2 = it.sum_r2;
-        do {
-            const double x = (t_next - t_old) / hd;
-            const double p2 = x * x, p3 = p2 * x, p4 = p3 * x;  // cumprod
-            const double S = hd * (Q0 * x + Q1 * p2 + Q2 * p3 + Q3 * p4) + y_old;
-            const double P_model = it.S0 - S;
-            if (WRITE_PRED) pred[i_out] = P_model;
-            const double r = s_P[base + i_out] - P_model;
-            sum_r2 += r * r;
-            ++i_out;
-            t_next = (i_out < n_t) ? s_t[base + i_out] : __longlong_as_double(0x7ff0000000000000LL);
-        } while (t_next <= t_new);
-        it.sum_r2 = sum_r2;
-        it.i_out = i_out;
-        it.t_next = t_next;
+        // x = (t_eval - t_old) / h (rk.py:566) by the six-operation division when its operands are safely inside the
+        // normal range: h itself, and the numerator, which is either 0 (t_eval == t_old, first step only), or t_eval
+        // (t_old == 0: smc_set_model_mm admits only data times that are 0 or >= 2^-400 in magnitude), or at least one
+        // ulp of |t_old| >= 2^-400.  Two copies of the loop rather than a select per output.
+        const bool lean_x = (DIV != kDivIeee) && hd >= 0x1p-400 && hd <= 0x1p400 &&
+                            (t_old == 0.0 || fabs(t_old) >= 0x1p-400);
+        if (lean_x)
+            mm_dense_outputs<WRITE_PRED, true>(it, s_tp, t_old, t_new, hd, y_old, Q0, Q1, Q2, Q3, pred);
+        else
+            mm_dense_outputs<WRITE_PRED, false>(it, s_tp, t_old, t_new, hd, y_old, Q0, Q1, Q2, Q3, pred);
         }
     }
     double fac_acc = py_min(10.0, pw);

@@ -244,6 +244,9 @@ int smc_set_model_mm(smc_ctx *c, const double *t, const double *P_obs, const dou
     for (int e = 0; e < n_ex; ++e)
         for (int i = 1; i < n_t; ++i)
             if (!(t[e * n_t + i] > t[e * n_t + i - 1])) return fail(c, "t must be strictly increasing (ivp.py:606-609)");
+    for (int i = 0; i < n_ex * n_t; ++i)   // the dense-output division relies on it (mm_rk45.h, lean_x)
+        if (!(t[i] == 0.0 || (fabs(t[i]) >= 0x1p-400 && fabs(t[i]) <= 0x1p400)))
+            return fail(c, "data times must be 0 or between 2^-400 and 2^400 in magnitude");
     HIPC(c, hipSetDevice(c->device));
     (void)hipFree(c->d_t);
     (void)hipFree(c->d_P);
