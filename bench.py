@@ -112,21 +112,49 @@ def cpu_baseline(sample_seconds_target=15.0):
             "ess_iters_per_s_n1e6_1core": 1.0 / dt_e}
 
 
+# the translation unit of the Michaelis-Menten kernels: mm_kernels.hip and everything it includes
+MM_KERNEL_SOURCES = ("csrc/mm_kernels.hip", "csrc/mm_rk45.h", "csrc/philox.h", "csrc/prior.h", "csrc/smc_internal.h",
+                     "include/smc_hip.h")
+
+
 def kernel_source_sha(root=None):
-    """sha256 over the CODE libsmc_hip.so is built from (comments and white space stripped, so that editing a comment does not
-    pretend to be a new kernel): ties a profile (profiles/*pmc*summary.json) to a kernel revision."""
+    """sha256 over the CODE the Michaelis-Menten kernels are compiled from (MM_KERNEL_SOURCES; comments and white space
+    stripped, so that editing a comment does not pretend to be a new kernel): ties a profile
+    (profiles/*pmc*summary.json) to a kernel revision."""
     import re
     root = root or ROOT
     h = hashlib.sha256()
-    csrc = os.path.join(root, os.path.basename(entry.PKG_DIR), "csrc")
-    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) +
-                    [os.path.join(root, "include", "smc_hip.h")]):
+    for rel in MM_KERNEL_SOURCES:
+        f = os.path.join(root, rel) if rel.startswith("include/") else os.path.join(root, os.path.basename(entry.PKG_DIR), rel)
         txt = open(f, encoding="utf-8", errors="replace").read()
         txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)          # block comments
         txt = re.sub(r"//[^\n]*", " ", txt)                        # line comments (no string literal of the sources holds //)
         h.update(os.path.basename(f).encode())
         h.update(" ".join(txt.split()).encode())
     return h.hexdigest()[:16]
+
+
+def measured_valu_issue(n_local):
+    """Vector-ALU occupancy of the solve kernel from the newest committed SQ counter summary (tools/pmc_sq_summary.py), only
+    if it was taken on THIS kernel revision; otherwise (None, why).  The algorithmic-flop fraction in `roofline.frac` says how
+    much of the FP64 peak the method's arithmetic uses; this says how busy the vector units are with everything the kernel
+    issues (divisions as six operations, step controller, dense output, scheduling) - the number that tells whether there is
+    idle issue capacity left."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_summary.json")))
+    if not files:
+        return None, "no SQ counter summary under profiles/"
+    f = files[-1]
+    try:
+        d = json.load(open(f))
+        if d["meta"].get("kernel_source_sha") != kernel_source_sha():
+            return None, f"{os.path.basename(f)} was taken on another kernel revision ({d['meta'].get('kernel_source_sha')})"
+        keep = ("valu_busy_fraction", "valu_issue_floor_fraction", "lane_utilisation", "fp64_share_of_valu_instructions",
+                "shader_clock_GHz")
+        out = {k: d["derived"][k] for k in keep}
+        out["workload"] = d["meta"].get("command")
+        return out, f"rocprofv3 --pmc SQ_* passes ({os.path.basename(f)})"
+    except (KeyError, ValueError, OSError) as e:
+        return None, f"{os.path.basename(f)}: {e!r}"
 
 
 def measured_traffic(kernel, n_local):
@@ -444,14 +472,18 @@ def main():
         w_cov = s.w_cov()
         ts = time.perf_counter()
         n_ss = 10
+        att_ss = 0
         for j in range(n_ss):                  # the fused iteration run_smc uses: moments -> factor -> propose -> solve -> accept
-            eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 424242, j, 0)
+            att_ss += eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 424242, j, 0)["rk_attempts"]
         eng.synchronize()
         dt_ss = time.perf_counter() - ts
         tm_ss = eng.timing_get()
+        ss_solve_s = tm_ss["solve"]["ms"] / n_ss * 1e-3
+        ss_tflops = (FLOP_PER_RK_ATTEMPT * att_ss / n_ss + FLOP_PER_PARTICLE_FIXED * n_local) / ss_solve_s / 1e12
         steady = {"particle_mutation_steps_per_s_wall": n_ss * n_local / dt_ss,
                   "solve_kernel_ms_per_sweep": tm_ss["solve"]["ms"] / n_ss,
-                  "sweep_ms_wall": 1e3 * dt_ss / n_ss, "sweeps": n_ss}
+                  "sweep_ms_wall": 1e3 * dt_ss / n_ss, "sweeps": n_ss, "rk_attempts_per_sweep": att_ss / n_ss,
+                  "solve_kernel_tflops": ss_tflops, "solve_kernel_roofline_frac": ss_tflops / FP64_VECTOR_PEAK_TFLOPS}
         eng.timing_enable(False)
 
     pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)          # global count
@@ -473,6 +505,7 @@ def main():
         hbm_gbps = HBM_BYTES_PER_PARTICLE_SOLVE * n_local / (solve_ms * 1e-3) / 1e9
         ess_ms = timing["ess"]["ms"]
         traffic, traffic_note = measured_traffic("void smc::mm_solve_kernel<false>", n_local)
+        valu, valu_note = measured_valu_issue(n_local)
         ess_l = timing["ess"]["launches"]
         ess_avg_ms = ess_ms / max(1, ess_l)
         result = {
@@ -497,7 +530,7 @@ def main():
                                        "which is the `peak` below; the HBM side is in `hbm`",
                          "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel_source_sha": kernel_source_sha(),
+                         "kernel_source_sha": kernel_source_sha(), "valu_issue": valu, "valu_issue_note": valu_note,
                          "peak_measured_fp64_fma_tflops": 57.3,
                          "avg_launch_ms": solve_ms, "launches": sv["launches"], "mh_sweep_avg_ms": mh_ms,
                          "algorithmic_flop_per_launch": flop_per_launch,

@@ -35,6 +35,34 @@ def test_random_data_shapes_vs_checker(pkg, O, seed):
 
 
 @pytest.mark.gpu
+def test_largest_data_set_vs_checker(pkg, O):
+    """16 experiments x 256 data times: the (time, observation) table of the solve kernel takes 66 KB of LDS, above the
+    default 64 KB limit of a launch."""
+    rs = np.random.RandomState(77)
+    n_ex, n_t, n = 16, 256, 192
+    t = np.sort(rs.uniform(0, 12, (n_ex, n_t)), axis=1)
+    t[::2, 0] = 0.0
+    S0 = rs.uniform(0.05, 3.0, n_ex)
+    P_obs = rs.uniform(0, 2, (n_ex, n_t))
+    data = O.MMData(t=t, P_obs=P_obs, S0=S0)
+    th = np.column_stack([rs.uniform(0.05, 10, n), rs.uniform(0.05, 10, n), rs.uniform(0.01, 5, n)])
+    ref = O.mm_loglik_batch(th, data, est_sigma=True, sigma_fixed=0.7)[0]
+    with pkg.HipEngine(n, 3, device=0) as eng:
+        eng.set_model_mm(t, P_obs, S0)
+        lk, pred, info = eng.loglik_host(th, want_pred=True)
+    assert info["n_failed"] == 0 and pred.shape == (n, n_ex, n_t) and np.isfinite(pred).all()
+    assert np.max(np.abs(lk - ref) / np.maximum(1.0, np.abs(ref))) < TOL
+
+
+@pytest.mark.gpu
+def test_data_times_outside_the_supported_range_are_refused(pkg):
+    t = np.array([[0.0, 1e-200, 1.0, 2.0]])
+    with pkg.HipEngine(8, 3, device=0) as eng:
+        with pytest.raises(pkg.SmcError, match="data times"):
+            eng.set_model_mm(t, np.zeros_like(t), np.array([1.0]))
+
+
+@pytest.mark.gpu
 def test_repeated_output_time_is_refused(pkg):
     t = np.array([[0.0, 1.0, 1.0, 2.0]])
     with pkg.HipEngine(8, 3, device=0) as eng:

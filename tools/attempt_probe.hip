@@ -13,15 +13,15 @@ using namespace smc;
 template <int DIV>
 __global__ void __launch_bounds__(64) solve_lanes(const double *theta, const double *t, const double *P, int n_t, int nlive,
                                                   double *out, int *att) {
-    __shared__ double s_t[256], s_P[256];
-    for (int i = threadIdx.x; i < n_t; i += 64) { s_t[i] = t[i]; s_P[i] = P[i]; }
+    __shared__ double2 s_tp[257];
+    mm_table_fill(s_tp, t, P, 1, n_t, threadIdx.x, 64);
     __syncthreads();
     if ((int)threadIdx.x >= nlive) return;
     const double Vmax = theta[threadIdx.x], Km = theta[64 + threadIdx.x], S0 = theta[128 + threadIdx.x];
     MMItem it;
-    if (!mm_item_begin<false>(it, Vmax, Km, S0, s_t, s_P, 0, n_t, 1e-3, 1e-6, nullptr)) return;
+    if (!mm_item_begin<false>(it, Vmax, Km, S0, s_tp, 0, n_t, 1e-3, 1e-6, nullptr)) return;
     int st;
-    do { st = mm_item_attempt<false, DIV>(it, s_t, s_P, n_t, 1e-3, 1e-6, nullptr); } while (st == 0);
+    do { st = mm_item_attempt<false, DIV>(it, s_tp, n_t, 1e-3, 1e-6, nullptr); } while (st == 0);
     out[threadIdx.x] = it.sum_r2;
     att[threadIdx.x] = it.attempts;
 }
@@ -35,14 +35,14 @@ __global__ void __launch_bounds__(256) busy_kernel(double *out, int iters) {   /
 template <int DIV>
 __global__ void __launch_bounds__(64) solve_one(double Vmax, double Km, double S0, const double *t, const double *P, int n_t,
                                                 int nlive, double *out, int *att) {
-    __shared__ double s_t[256], s_P[256];
-    for (int i = threadIdx.x; i < n_t; i += 64) { s_t[i] = t[i]; s_P[i] = P[i]; }
+    __shared__ double2 s_tp[257];
+    mm_table_fill(s_tp, t, P, 1, n_t, threadIdx.x, 64);
     __syncthreads();
     if ((int)threadIdx.x >= nlive) return;
     MMItem it;
-    if (!mm_item_begin<false>(it, Vmax, Km, S0, s_t, s_P, 0, n_t, 1e-3, 1e-6, nullptr)) return;
+    if (!mm_item_begin<false>(it, Vmax, Km, S0, s_tp, 0, n_t, 1e-3, 1e-6, nullptr)) return;
     int st;
-    do { st = mm_item_attempt<false, DIV>(it, s_t, s_P, n_t, 1e-3, 1e-6, nullptr); } while (st == 0);
+    do { st = mm_item_attempt<false, DIV>(it, s_tp, n_t, 1e-3, 1e-6, nullptr); } while (st == 0);
     out[threadIdx.x] = it.sum_r2;
     att[threadIdx.x] = it.attempts;
 }
