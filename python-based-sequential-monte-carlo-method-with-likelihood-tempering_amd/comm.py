@@ -42,7 +42,7 @@ class RcclComm:
     """Collectives of the HipEngine's RCCL communicator.
 
     bootstrap(rank0_bytes_or_None) -> bytes must broadcast rank 0's 128-byte unique id to every rank
-    (bench.py does this with torch.distributed's store; any out-of-band channel works).
+    (bench.py does this through a file in a directory the ranks share; any out-of-band channel works).
     """
 
     on_device = True      # reductions run inside the engine: RCCL in place on its stream (driver._on_device)
