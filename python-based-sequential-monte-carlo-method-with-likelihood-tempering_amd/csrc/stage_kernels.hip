@@ -158,30 +158,63 @@ struct EssCand {
     int k;
 };
 
+// Sums NV values per lane over the 64 lanes of a wave by a transposing butterfly: at every step a lane hands half of its
+// values to its partner (lane ^ offset) and adds the partner's copy of the half it keeps, so the number of live values
+// halves while the offset halves; once one value is left the remaining steps are plain exchanges.  NV - 1 + log2(64 / NV)
+// additions per lane instead of 6 NV; afterwards lane l holds the wave total of value l >> (6 - log2 NV) in v[0].
+// (The epilogue of the ESS pass used to be 32 block-wide sums, each with its own shuffles, LDS hop and two barriers: about
+// twice the instructions of the pass over the particles itself.)
+template <int NV, int CNT, int OFF>
+struct WaveSumStep {   // one step of the butterfly: CNT live values, partner lane ^ OFF (recursion = guaranteed unrolling)
+    static __device__ __forceinline__ void run(double (&v)[NV], int lane) {
+        if constexpr (CNT > 1) {
+            constexpr int half = CNT / 2;
+            const bool upper = (lane & OFF) != 0;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const double keep = upper ? v[i + half] : v[i];
+                const double give = upper ? v[i] : v[i + half];
+                v[i] = keep + __shfl_xor(give, OFF);
+            }
+        } else {
+            v[0] += __shfl_xor(v[0], OFF);
+        }
+        if constexpr (OFF > 1) WaveSumStep<NV, (CNT > 1 ? CNT / 2 : 1), OFF / 2>::run(v, lane);
+    }
+};
+template <int NV>
+__device__ __forceinline__ void wave_sum_transposed(double (&v)[NV], int lane) {
+    static_assert(NV >= 1 && NV <= 64 && (NV & (NV - 1)) == 0, "NV must be a power of two");
+    WaveSumStep<NV, NV, 32>::run(v, lane);
+}
+
 template <int K>
 __global__ void __launch_bounds__(kScanBlock) ess_partial_kernel(const double *__restrict__ lk, int64_t n, double max_lk,
                                                                  EssCand cand, double *__restrict__ partials) {
-    __shared__ double lds[4];
-    double s1[K], s2[K];
+    constexpr int NV = 2 * K;                          // value 2k = sum of weights, 2k + 1 = sum of squared weights
+    constexpr int kShift = NV == 2 ? 5 : NV == 8 ? 3 : NV == 16 ? 2 : 1;   // 6 - log2(NV)
+    static_assert(NV == 2 || NV == 8 || NV == 16 || NV == 32, "K must be 1, 4, 8 or 16");
+    __shared__ double s_part[kScanBlock / 64][NV];
+    double v[NV];
 #pragma unroll
-    for (int k = 0; k < K; ++k) s1[k] = s2[k] = 0.0;
+    for (int k = 0; k < NV; ++k) v[k] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double d = lk[i] - max_lk;  // d_lk (:118)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const double w = exp(d * cand.gm[k]);  // :124
-            s1[k] += w;
-            s2[k] += w * w;
+            v[2 * k] += w;
+            v[2 * k + 1] += w * w;
         }
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double a = block_sum(s1[k], lds);
-        const double b = block_sum(s2[k], lds);
-        if (threadIdx.x == 0) {
-            partials[((size_t)blockIdx.x * K + k) * 2 + 0] = a;
-            partials[((size_t)blockIdx.x * K + k) * 2 + 1] = b;
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_sum_transposed<NV>(v, lane);
+    if ((lane & ((1 << kShift) - 1)) == 0) s_part[wave][lane >> kShift] = v[0];
+    __syncthreads();
+    if (threadIdx.x < NV) {                            // the waves of the block in fixed order
+        double r = s_part[0][threadIdx.x];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += s_part[w][threadIdx.x];
+        partials[(size_t)blockIdx.x * NV + threadIdx.x] = r;
     }
 }
 // sums nvals interleaved values over np partial rows: one block per value (round 1 had ONE block walk through all values,
@@ -618,8 +651,9 @@ __global__ void resample_stale_rows_kernel(const double *__restrict__ src_theta,
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-// blocks of a grid-stride reduction: 2048 (8 per CU) for the passes that only stream, 512 (2 per CU) for the ESS pass, whose
-// block epilogue - 2K block sums for K candidates - dominated at 2048 (measured 256 .. 2048: profiles/r02_ess_bench.log)
+// blocks of a grid-stride reduction: 2048 (8 per CU) for the passes that only stream, 512 (2 per CU) for the ESS pass (measured
+// 128 .. 4096 with the transposing wave reduction in place: profiles/r02_ess_bench.log; more blocks mean more rows for the
+// final sum, fewer leave SIMDs idle)
 static inline int reduce_grid(int64_t n, int cap = 2048) {
     static const int ess_cap = getenv("SMC_REDUCE_BLOCKS") ? atoi(getenv("SMC_REDUCE_BLOCKS")) : 512;
     if (cap == 512) cap = ess_cap;
@@ -674,6 +708,8 @@ void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const do
         hipLaunchKernelGGL((ess_partial_kernel<16>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
                            c->d_partials);
     }
+    // a second launch for the 2K sums over the blocks' rows: letting the last block to finish do it (ticket + __threadfence)
+    // was tried and is 30 us SLOWER per pass - the fence writes back and invalidates the XCD's L2 in every block
     hipLaunchKernelGGL(sum_rows_final_kernel, dim3(2 * K), dim3(kScanBlock), 0, c->stream, c->d_partials, g, 2 * K, d_out);
 }
 int ess_padded_k(int k) { return k <= 1 ? 1 : k <= 4 ? 4 : k <= 8 ? 8 : 16; }
