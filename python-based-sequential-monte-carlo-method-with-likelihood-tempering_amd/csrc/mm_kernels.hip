@@ -193,8 +193,13 @@ __device__ __forceinline__ double lane_value(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+#ifdef SMC_SOLVE_WAVES   // A/B knob: waves per SIMD the register allocation is limited to
+#define SMC_SOLVE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SMC_SOLVE_WAVES, SMC_SOLVE_WAVES)))
+#else
+#define SMC_SOLVE_WAVES_ATTR
+#endif
 template <bool WRITE_PRED>
-__global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, SolveArgs a) {
+__global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_kernel(MMModel mm, SolveArgs a) {
     extern __shared__ double2 smem_tp[];
     const int n_ex = mm.n_ex, n_t = mm.n_t;
     double2 *s_tp = smem_tp;                                        // n_ex rows of n_t + 1 (time, P_obs) pairs, mm_rk45.h
