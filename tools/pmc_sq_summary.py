@@ -32,6 +32,7 @@ def collect(directory, kernel, last):
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no *counter_collection.csv under {directory}")
+    files = [max(files, key=os.path.getmtime)]        # one run per directory: the newest (gpurun merges, it never deletes)
     rows = [r for f in files for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
     ids = sorted({int(r["Dispatch_Id"]) for r in rows})
     if last:

@@ -28,7 +28,7 @@ def per_kernel(directory, counter):
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no *counter_collection.csv under {directory}")
-    for f in files:
+    for f in [max(files, key=os.path.getmtime)]:      # one run per directory: the newest (gpurun merges, it never deletes)
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
