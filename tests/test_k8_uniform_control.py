@@ -77,3 +77,21 @@ def test_k8_loop_control_is_wave_uniform(src, kernel, tmp_path):
     assert unexplained == [], f"{kernel}: divergent branches that do not come from the lane id: {unexplained[:5]}"
     assert n_branches > 0        # the lane-id branches (if (node) ...) are still there: the parser saw the kernel
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def test_no_dequeue_behind_a_lane_id_branch():
+    """The two hangs of this code base (profiles/r02_k8_dequeue_hang_isa.md) had one source shape: a value produced under
+    `if (lane == 0)` (an atomicAdd on a work queue) and then read by every lane through v_readfirstlane / __shfl.  The
+    compiler may separate the two sides of such a branch.  No source file may contain that shape again."""
+    csrc = CSRC
+    bad = []
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, name), encoding="utf-8").read()
+        text = re.sub(r"//[^\n]*", "", text)
+        for m in re.finditer(r"if\s*\(\s*(lane|threadIdx\.x\s*&\s*63|l)\s*==\s*0\s*\)\s*\{?[^;{}]*=\s*atomicAdd", text):
+            tail = text[m.end():m.end() + 400]
+            if re.search(r"readfirstlane|__shfl\s*\(", tail):
+                bad.append(f"{name}: ...{text[m.start():m.end()]}...")
+    assert not bad, bad
