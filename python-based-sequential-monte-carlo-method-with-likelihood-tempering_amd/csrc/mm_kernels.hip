@@ -108,7 +108,12 @@ static_assert(kChunk % 64 == 0, "the chunk dequeue adds kChunk / 64 per lane");
 #ifndef SMC_REFILL_AT
 #define SMC_REFILL_AT 24
 #endif
-constexpr int kRefillAt = SMC_REFILL_AT;      // refill a wave once this many lanes are idle (or none is live)
+constexpr int kRefillAt = SMC_REFILL_AT;   // idle lanes that make a wave look at its pool (and refill it when it is empty)
+#ifndef SMC_POOL_FREE
+#define SMC_POOL_FREE 48
+#endif
+constexpr int kPoolRefillFree = SMC_POOL_FREE;   // free pool slots that trigger the start of that many new items
+constexpr int kPoolWords = 15;            // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer      // refill a wave once this many lanes are idle (or none is live)
 
 struct SolveArgs {
     const double *theta;        // SoA rows: Vmax at [p], Km at [stride + p], sigma at [2*stride + p]
@@ -207,6 +212,12 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     mm_table_fill(s_tp, mm.t, mm.P_obs, n_ex, n_t, threadIdx.x, blockDim.x);
     if (threadIdx.x < n_ex) s_S0[threadIdx.x] = mm.S0[threadIdx.x];
     __syncthreads();
+    // The wave's pool of STARTED items (mm_item_begin done, no attempt yet): a ring of 64 slots in LDS, word-major so that
+    // lanes reading or writing consecutive slots hit consecutive banks.  Starting items and running them are decoupled:
+    // items are started 48 or more at a time by lanes 0 .. take-1 whatever those lanes are running (the start-up code -
+    // index arithmetic, three loads, select_initial_step with its nine IEEE divisions - used to run with 24 of 64 lanes
+    // active), and a lane that finishes takes its next item from the pool after at most a few attempts of waiting.
+    double *s_pool = s_S0 + ((n_ex + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kPoolWords * kWave);
 
     // items are laid out in groups of 64 particles x n_ex experiments; the last group may be partial
     const unsigned long long n_blk = (unsigned long long)((a.n + kWave - 1) / kWave);
@@ -230,11 +241,11 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     int q_e = 0;                            // ... and experiment (one 64-bit division per chunk, none per hand-out)
     bool drained = false;                   // the global queue is empty
 
+    int pool_head = 0, pool_count = 0;      // the ring of started items: slots [head, head + count) mod 64 (wave-uniform)
+
     for (;;) {
-        const unsigned long long live_mask = __ballot(live);
-        const int n_idle = kWave - __popcll(live_mask);
-        bool handed_out = false;
-        if (!drained && n_idle >= kRefillAt) {
+        // ---- start new items into the pool ------------------------------------------------------------------
+        if (!drained && kWave - pool_count >= kPoolRefillFree) {
             if (q_lo == q_hi) {  // next chunk: one atomic per wave and kChunk items
                 // No `if (lane == 0)` around the atomic: the compiler may split such a branch from the v_readfirstlane
                 // that follows it and let the other lanes run ahead with b = 0 (profiles/r02_k8_dequeue_hang_isa.md has
@@ -255,14 +266,15 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
                 q_blk = q_grp - (unsigned long long)q_e * n_blk;
             }
             if (!drained) {
-                const unsigned long long idle_mask = ~live_mask;
                 const unsigned long long avail = q_hi - q_lo;
-                const int my = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
-                                                              __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
-                const int take = (unsigned long long)n_idle < avail ? n_idle : (int)avail;
-                handed_out = true;
-                if (!live && my < take) {
-                    const unsigned long long item = q_lo + my;
+                const int free_slots = kWave - pool_count;
+                const int take = (unsigned long long)free_slots < avail ? free_slots : (int)avail;
+                bool started = false;               // this lane's new item needs attempts: it goes into the pool
+                MMItem nb;
+                int64_t nb_idx = 0;
+                double *nb_pred = nullptr;
+                if (lane < take) {
+                    const unsigned long long item = q_lo + lane;
                     // 64-item group = (experiment, block of 64 particles); a chunk spans at most three groups
                     unsigned long long blk = q_blk + ((item >> 6) - q_grp);
                     int e = q_e;
@@ -270,22 +282,22 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
                     if (blk >= n_blk) { blk -= n_blk; ++e; }
                     const int64_t p = (int64_t)blk * kWave + (int64_t)(item & 63);
                     if (p < a.n) {
-                        out_idx = (int64_t)e * a.n + p;
+                        nb_idx = (int64_t)e * a.n + p;
                         bool run = true;
                         if (a.p0 && a.p0[p] == 0) run = false;          // masked proposal: lk2 == lk1, no solve
                         const double Vmax = a.theta[p], Km = a.theta[a.stride + p];
                         const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
                         if (sigma <= 0.0) run = false;                   // -inf without solving (:53-54)
                         if (run) {
-                            if (WRITE_PRED) pred_item = a.pred + ((size_t)p * n_ex + e) * n_t;
-                            live = mm_item_begin<WRITE_PRED>(it, Vmax, Km, s_S0[e], s_tp, mm_table_row(e, n_t), n_t, rtol, atol,
-                                                             pred_item);
-                            if (!live) {  // nothing to integrate: finished at once
-                                const bool ok = (it.i_out == n_t);
-                                publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), ok ? 0 : kInfoFailed);
+                            if (WRITE_PRED) nb_pred = a.pred + ((size_t)p * n_ex + e) * n_t;
+                            started = mm_item_begin<WRITE_PRED>(nb, Vmax, Km, s_S0[e], s_tp, mm_table_row(e, n_t), n_t, rtol,
+                                                                atol, nb_pred);
+                            if (!started) {  // nothing to integrate: finished at once
+                                const bool ok = (nb.i_out == n_t);
+                                publish_item(a, nb_idx, ok ? nb.sum_r2 : quiet_nan(), ok ? 0 : kInfoFailed);
                             }
                         } else {
-                            publish_item(a, out_idx, 0.0, 0);
+                            publish_item(a, nb_idx, 0.0, 0);
                             if (WRITE_PRED) {
                                 double *pp = a.pred + ((size_t)p * n_ex + e) * n_t;
                                 for (int i = 0; i < n_t; ++i) pp[i] = quiet_nan();
@@ -293,11 +305,70 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
                         }
                     }
                 }
+                const unsigned long long started_mask = __ballot(started);
+                if (started) {
+                    const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(started_mask >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)started_mask, 0u));
+                    double *slot = s_pool + ((pool_head + pool_count + r) & (kWave - 1));
+                    slot[0 * kWave] = nb.negVmax;
+                    slot[1 * kWave] = nb.Km;
+                    slot[2 * kWave] = nb.S0;
+                    slot[3 * kWave] = nb.t;
+                    slot[4 * kWave] = nb.y;
+                    slot[5 * kWave] = nb.f;
+                    slot[6 * kWave] = nb.h_abs;
+                    slot[7 * kWave] = nb.min_step;
+                    slot[8 * kWave] = nb.t_bound;
+                    slot[9 * kWave] = nb.t_next;
+                    slot[10 * kWave] = nb.sum_r2;
+                    slot[11 * kWave] = __hiloint2double(nb.i_out, nb.t_off);
+                    slot[12 * kWave] = __hiloint2double((int)nb.rejected, nb.attempts);
+                    slot[13 * kWave] = __longlong_as_double((long long)nb_idx);
+                    if (WRITE_PRED) slot[14 * kWave] = __longlong_as_double((long long)nb_pred);
+                }
+                pool_count += __popcll(started_mask);
                 q_lo += take;
             }
         }
-        if (drained) {
-            // tail: no item is left to hand out.  What remains are the long serial chains of stiff items.
+        // ---- idle lanes take started items from the pool (LDS operations of one wave execute in order) ------------
+        __builtin_amdgcn_wave_barrier();
+        {
+            const unsigned long long idle_mask = ~__ballot(live);
+            const int n_idle = __popcll(idle_mask);
+            if (pool_count > 0 && n_idle > 0) {
+                const int k = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
+                const int n_take = n_idle < pool_count ? n_idle : pool_count;
+                if (!live && k < n_take) {
+                    const double *slot = s_pool + ((pool_head + k) & (kWave - 1));
+                    it.negVmax = slot[0 * kWave];
+                    it.Km = slot[1 * kWave];
+                    it.S0 = slot[2 * kWave];
+                    it.t = slot[3 * kWave];
+                    it.y = slot[4 * kWave];
+                    it.f = slot[5 * kWave];
+                    it.h_abs = slot[6 * kWave];
+                    it.min_step = slot[7 * kWave];
+                    it.t_bound = slot[8 * kWave];
+                    it.t_next = slot[9 * kWave];
+                    it.sum_r2 = slot[10 * kWave];
+                    const double w11 = slot[11 * kWave], w12 = slot[12 * kWave];
+                    it.t_off = __double2loint(w11);
+                    it.i_out = __double2hiint(w11);
+                    it.attempts = __double2loint(w12);
+                    it.rejected = __double2hiint(w12) != 0;
+                    out_idx = (int64_t)__double_as_longlong(slot[13 * kWave]);
+                    if (WRITE_PRED) pred_item = (double *)__double_as_longlong(slot[14 * kWave]);
+                    live = true;
+                }
+                pool_head = (pool_head + n_take) & (kWave - 1);
+                pool_count -= n_take;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!drained && pool_count == 0 && __ballot(live) == 0ull) continue;   // every started item was done at once: start more
+        if (drained && pool_count == 0) {
+            // tail: no item is left to hand out or to take from the pool.  What remains are the long serial chains of stiff items.
             // A wave that holds exactly ONE of them (the usual case: they are 1 in 10^3 .. 10^4 items) runs it with the
             // item's state broadcast to the whole wave through v_readlane: every operand is then wave-uniform, the
             // compiler turns the accept / reject / output branches into scalar branches and drops the per-lane selects,
@@ -392,10 +463,9 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
             }
             break;
         }
-        if (handed_out && __ballot(live) == 0ull) continue;   // otherwise fewer than kRefillAt lanes are idle: some lane is live
-        // attempts of the live lanes until kRefillAt lanes are idle again: a tight inner loop (item state stays in its
-        // registers, one ballot and one scalar branch per attempt) - the scheduling logic above runs once per hand-out,
-        // not once per attempt
+        // attempts of the live lanes until kRefillAt lanes are idle (they then take items from the pool, which is refilled
+        // above when it runs low): a tight inner loop (item state stays in its registers, one ballot and one scalar branch
+        // per attempt) - the scheduling logic above runs once per hand-out, not once per attempt
         int idle_now;
         do {
             if (live) {
@@ -548,6 +618,12 @@ static unsigned finish_grid(int64_t n) {
     return (unsigned)(g < 1024 ? (g < 1 ? 1 : g) : 1024);
 }
 
+// dynamic LDS of the solve kernel: the (time, observation) table, S0, and the four waves' pools of started items
+static size_t solve_lds_bytes(int n_ex, int n_t) {
+    return (size_t)n_ex * (n_t + 1) * sizeof(double2) + (size_t)((n_ex + 1) & ~1) * sizeof(double) +
+           (size_t)(kSolveBlock / kWave) * kPoolWords * kWave * sizeof(double);
+}
+
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
                          bool queue_cleared = false, const MHParams *mh_reject = nullptr) {
     const MMModel &mm = ctx->mm;
@@ -572,14 +648,14 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
         a.prior_mode = mh_reject->prior_mode;
     }
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
-    const size_t lds = (size_t)mm.n_ex * (mm.n_t + 1) * sizeof(double2) + (size_t)mm.n_ex * sizeof(double);
-    if (lds > 48 * 1024) {   // the largest data set (16 x 256) needs 66 KB of the CU's 160 KB: above the default dynamic limit
+    const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
+    if (lds > 48 * 1024) {   // the largest data set (16 x 256) needs 66 + 30 KB of the CU's 160 KB: above the default dynamic limit
         static bool raised = false;
         if (!raised) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             raised = true;
         }
     }
@@ -632,7 +708,7 @@ int query_solve_blocks_per_cu() {
         if (v >= 1) return v;
     }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false>, kSolveBlock, 4096) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false>, kSolveBlock, solve_lds_bytes(6, 40)) != hipSuccess || nb < 1)
         nb = 2;
     return nb;
 }
