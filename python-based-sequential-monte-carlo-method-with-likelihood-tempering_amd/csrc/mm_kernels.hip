@@ -103,7 +103,10 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
 // solve: persistent waves, lane-level dynamic scheduling
 // ---------------------------------------------------------------------------------------------
 constexpr int kSolveBlock = 256;   // 4 waves
-constexpr int kChunk = 128;        // items per global dequeue (2 per lane)
+#ifndef SMC_CHUNK
+#define SMC_CHUNK 128
+#endif
+constexpr int kChunk = SMC_CHUNK;    // items per global dequeue (2 per lane)
 static_assert(kChunk % 64 == 0, "the chunk dequeue adds kChunk / 64 per lane");
 #ifndef SMC_REFILL_AT
 #define SMC_REFILL_AT 24
@@ -275,11 +278,12 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
                 double *nb_pred = nullptr;
                 if (lane < take) {
                     const unsigned long long item = q_lo + lane;
-                    // 64-item group = (experiment, block of 64 particles); a chunk spans at most three groups
+                    // 64-item group = (experiment, block of 64 particles); a chunk spans kChunk / 64 + 1 groups at most
                     unsigned long long blk = q_blk + ((item >> 6) - q_grp);
                     int e = q_e;
-                    if (blk >= n_blk) { blk -= n_blk; ++e; }
-                    if (blk >= n_blk) { blk -= n_blk; ++e; }
+#pragma unroll
+                    for (int w = 0; w < kChunk / 64 + 1; ++w)
+                        if (blk >= n_blk) { blk -= n_blk; ++e; }
                     const int64_t p = (int64_t)blk * kWave + (int64_t)(item & 63);
                     if (p < a.n) {
                         nb_idx = (int64_t)e * a.n + p;
