@@ -7,12 +7,14 @@
 //   mm_propose_kernel   (MH only)  proposal = p_filt + noise*ratio, prior support mask, reset of
 //                       out-of-support proposals (:220-228).  HBM-bound, ~60 B/particle.
 //   mm_solve_kernel     one work item = one (particle, experiment) RK45 solve -> sum of squared
-//                       residuals.  FP64-VALU-bound: >99 % of the sweep.  PERSISTENT waves with
-//                       LANE-LEVEL dynamic scheduling: whenever enough lanes of a wave have finished
-//                       their item they are handed the next items of the wave's chunk; chunks come
-//                       from one global atomic counter (one atomic per 128 items).  Adaptive step
-//                       counts differ by 100x between particles over the prior; static mapping made
-//                       the early tempering steps 20-40x slower than the late ones (profiles/r01_a).
+//                       residuals.  FP64-VALU-bound (vector ALUs 86 % busy in the posterior phase): >99 % of
+//                       the sweep.  PERSISTENT waves with LANE-LEVEL dynamic scheduling: a wave starts items
+//                       48 or more at a time into a pool in LDS (chunks of 128 items come from one global
+//                       atomic counter) and lanes that finish an item take the next started one from the
+//                       pool.  Adaptive step counts differ by 100x between particles over the prior;
+//                       static mapping made the early tempering steps 20-40x slower than the late ones
+//                       (profiles/r01_a).  In Metropolis sweeps a solve is cancelled as soon as its proposal
+//                       is certain to be rejected (mm_certainly_rejected).
 //   mm_finish_kernel    per particle: the n_ex sums -> logL in experiment order (:70-73), then
 //                       either store it (likelihood sweep) or accept/select (:231-241).
 //
@@ -116,14 +118,14 @@ constexpr int kRefillAt = SMC_REFILL_AT;   // idle lanes that make a wave look a
 #define SMC_POOL_FREE 48
 #endif
 constexpr int kPoolRefillFree = SMC_POOL_FREE;   // free pool slots that trigger the start of that many new items
-constexpr int kPoolWords = 15;            // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer      // refill a wave once this many lanes are idle (or none is live)
+constexpr int kPoolWords = 15;            // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer
 
 struct SolveArgs {
     const double *theta;        // SoA rows: Vmax at [p], Km at [stride + p], sigma at [2*stride + p]
     int64_t stride, n;
     const uint8_t *p0;          // MH: support flags; items of particles with p0 == 0 are not solved
     double *sum_r2;             // [e*n + p]
-    int *info;                  // [e*n + p]: attempts | failed << 30
+    int *info;                  // [e*n + p]: attempts | cancelled << 29 | failed << 30
     double *pred;               // optional: P_model, [(p*n_ex + e)*n_t + i]
     unsigned long long *queue;  // global item counter (zeroed before the launch)
     // Exact early rejection (Metropolis sweeps only; lk1 == nullptr: off).  See mm_certainly_rejected().
