@@ -7,7 +7,7 @@ is already decided - against the proposal - by the OTHER experiments of the same
 attempts, i.e. within a millisecond) with the long solve counted as a perfect fit (sum of squared residuals 0), and how
 often such proposals are accepted at all.  Test infrastructure (uses oracle/); not part of the product.
 
-    python tools/early_reject_analysis.py [N=1000000] > profiles/r02_early_reject_analysis.log
+    python tests/early_reject_analysis.py [N=1000000] > profiles/r02_early_reject_analysis.log
 """
 import os
 import sys

@@ -1,7 +1,7 @@
 """Randomised soak of the Michaelis-Menten likelihood sweep against the CPU checker (a test tool, not product code): 160 cases
 with 1 .. 10^4 particles, 1 .. 8 experiments, 1 .. 60 data times, Km log-uniform over 1e-3 .. 10 (a quarter of the particles
 in the stiff band: tolerance as in tests/test_gpu_fuzz_shapes.py::test_stiff_band_parity_and_its_tolerance).
-  python tools/soak_mm.py      (about 25 s on an MI355X)"""
+  python tests/soak_mm.py      (about 25 s on an MI355X)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
