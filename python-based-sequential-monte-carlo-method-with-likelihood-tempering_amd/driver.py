@@ -232,20 +232,26 @@ def mvn_transform(cov_m):
     return np.sqrt(sv)[:, None] * v
 
 
-def _dump(dump_dir, name, arr, rank, world, header=None):
-    """Per-step particle dumps in the reference's format (np.savetxt(..., delimiter=','),
-    SMC_methanation_main.py:181,422; methanation_functions.py:232-234).  With several ranks every rank writes its
-    own block (suffix _rank<r>); concatenating them in rank order gives the reference's file."""
-    import os
-    os.makedirs(os.path.join(dump_dir, "pred"), exist_ok=True)
-    suffix = "" if world == 1 else f"_rank{rank}"
-    path = os.path.join(dump_dir, name + suffix + ".csv")
+def write_particles_csv(path, arr, header=None):
+    """One particle table in the reference's two on-disk formats: bare `np.savetxt(..., delimiter=',')`
+    (SMC_methanation_main.py:181,422; methanation_functions.py:233-234) or, with column names, the pandas CSV of
+    `Posterior_Distribution.csv` (methanation_functions.py:231-232).  The per-step dumps of run_smc and the drop-in
+    `SavePosteriorcsv` both write through here."""
     if header is None:
         np.savetxt(path, arr, delimiter=',')
     else:
         import pandas as pd
-        pd.DataFrame(arr, columns=header).to_csv(path, index=False)   # methanation_functions.py:231-232
+        pd.DataFrame(arr, columns=list(header)).to_csv(path, index=False)
     return path
+
+
+def _dump(dump_dir, name, arr, rank, world, header=None):
+    """Per-step particle dumps in the reference's format.  With several ranks every rank writes its
+    own block (suffix _rank<r>); concatenating them in rank order gives the reference's file."""
+    import os
+    os.makedirs(os.path.join(dump_dir, "pred"), exist_ok=True)
+    suffix = "" if world == 1 else f"_rank{rank}"
+    return write_particles_csv(os.path.join(dump_dir, name + suffix + ".csv"), arr, header)
 
 
 def _save_state(dump_dir, step, rank, world, state):

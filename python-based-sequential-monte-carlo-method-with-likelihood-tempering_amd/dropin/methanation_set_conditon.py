@@ -9,8 +9,11 @@ import numpy as np
 from smc_lt_amd import methanation as _M
 from smc_lt_amd.driver import SMCSettings as _SMCSettings
 
+import os as _os
+
 np.random.seed(20250205)
-_s = _SMCSettings()
+# n_particle can be overridden with the environment variable SMC_N_PARTICLE (the reference hard-codes 1000, :108)
+_s = _SMCSettings(n_particle=int(_os.environ.get("SMC_N_PARTICLE", "1000")))
 
 n_state = 9
 num_model_params = 8
