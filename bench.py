@@ -417,6 +417,8 @@ def main():
                          "of whole runs - the mode for config 4's full size, --particles-per-gpu 100000")
     ap.add_argument("--no-early-reject", action="store_true",
                     help="A/B switch: complete every solve even when its proposal is already certain to be rejected (SMCSettings.early_reject)")
+    ap.add_argument("--no-stiff-first", action="store_true",
+                    help="A/B switch: hand the (particle, experiment) solves out in plain index order (SMCSettings.stiff_first)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # no launcher: become one (no GPU call in this process)
@@ -434,7 +436,7 @@ def main():
     n_local = args.particles_per_gpu
     n_global = n_local * world
     t, P_obs, S0 = load_mm_data()
-    s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject)
+    s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first)
 
     # SMC_BENCH_DEVICE pins every rank to one device (rehearsing the multi-rank path on a one-GPU box)
     dev = int(os.environ.get("SMC_BENCH_DEVICE", local_rank))

@@ -136,6 +136,12 @@ int smc_set_prior_mode(smc_ctx *ctx, int mode);
  * capture therefore switches the feature off).  It removes the long solves that dominate the early tempering steps:
  * they are proposals with Vmax/Km in the thousands whose other experiments already rule them out. */
 int smc_set_early_reject(smc_ctx *ctx, int enable);
+/* Michaelis-Menten sweeps hand the predictably long solves (Vmax > 250 Km: RK45 runs on its stability limit for ~3.7 Vmax/Km
+ * attempts) out BEFORE the index-ordered items (default: on), so that the serial chain that bounds a sweep starts at its
+ * beginning.  The order in which independent (particle, experiment) solves run changes no result - the reference's
+ * one-Ray-task-per-particle fan-out (Micmem_likelihood.py:83-87) leaves it to its scheduler too; 0 restores round 2's
+ * plain index order (A/B timing, tests). */
+int smc_set_stiff_first(smc_ctx *ctx, int enable);
 int smc_set_resampling(smc_ctx *ctx, int scheme);
 
 /* ---- particle movement -------------------------------------------------------------------- */
@@ -194,6 +200,17 @@ int smc_download_offspring(smc_ctx *ctx, int64_t *p_is, int64_t n);
  * Slots >= total offspring keep the content the reference's persistent p_filt would hold
  * (zeros before the first tempering step, the previous p_pred row afterwards). */
 int smc_resample_phase3(smc_ctx *ctx, const int64_t *out_base_all, const int64_t *offspring_all, int first_step);
+/* The send / receive plan phase 3 executes on rank `rank` of `world` (host arithmetic only: needs neither a context nor a
+ * GPU).  Arrays of length world: send_off / send_cnt (one contiguous block per peer in the send staging, in particles),
+ * src_lo (first local offspring index of the block for peer q; for q == rank the block that stays), recv_off / recv_cnt
+ * (receive staging) and recv_row (first row of SMC_SET_FILT the block of peer q is spread over); own[3] = {src_lo, count,
+ * first row} of the offspring that stay on the rank; stale_lo = first row nobody writes (n_local if none).  Any output
+ * pointer may be NULL.  Returns 1 if out_base_all is not the exclusive prefix of offspring_all, 2 on bad arguments.
+ * Sender and receiver plans must agree - send_cnt of rank s towards r == recv_cnt of rank r from s - and every row of every
+ * rank must be written exactly once: tests/test_exchange_plan.py checks both for world sizes 2..8 without a GPU. */
+int smc_exchange_plan(int world, int rank, int64_t n_local, const int64_t *out_base_all, const int64_t *offspring_all,
+                      int64_t *send_off, int64_t *send_cnt, int64_t *src_lo, int64_t *recv_off, int64_t *recv_cnt,
+                      int64_t *recv_row, int64_t *own, int64_t *stale_lo);
 /* Micmem_SMC_main.py:147-184 across all ranks in one call: phase 1 -> all-gather of (residual sum, integer copies) ->
  * residual prefix of the lower ranks as a running sum in rank order (:165-167) -> phase 2 -> all-gather of the offspring
  * counts -> phase 3.  Two synchronisations instead of six.  n_offspring = sum of p_is over all particles (== N unless the

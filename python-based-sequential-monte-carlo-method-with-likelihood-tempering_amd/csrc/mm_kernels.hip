@@ -44,6 +44,32 @@ constexpr int kInfoAttemptsMask = 0x1fffffff, kInfoCancelled = 1 << 29, kInfoFai
 constexpr double kSumCancelled = -1.0;
 
 // ---------------------------------------------------------------------------------------------
+// the stiff list: solves that are predictably long start first
+// ---------------------------------------------------------------------------------------------
+// A solve with Vmax/Km = r runs on RK45's stability limit for ~3.7 r attempts (every solve above
+// 10^3 attempts of a 10^6-particle prior sample has r > 269): a serial chain of up to 8e4 attempts = 35 ms that no amount
+// of parallelism shortens.  What CAN be chosen is when it starts.  Handed out in index order, the chain that bounds a
+// sweep began wherever the queue happened to reach it - up to a whole bulk pass (1.3 ms of a 1.7 ms Metropolis sweep,
+// 4 ms of the initial sweep) late.  Particles above the threshold are therefore collected into a list while the proposal
+// is formed (or by mm_stiff_scan_kernel before a plain likelihood sweep) and mm_solve_kernel hands that list out before
+// the index-ordered items.  The order in which independent items are solved cannot change any result - the reference's
+// own fan-out (one Ray task per particle, Micmem_likelihood.py:83-87) leaves it to the scheduler as well.
+constexpr double kStiffRatio = 250.0;
+__device__ __forceinline__ bool mm_is_stiff(double Vmax, double Km) { return Km > 0.0 && Vmax > kStiffRatio * Km; }
+// One atomic per stiff lane on purpose: no cross-lane read follows it, so it is correct whether or not the compiler's
+// atomic optimiser folds the wave's atomics into one.  Every particle is appended at most once: the list cannot overflow.
+__device__ __forceinline__ void stiff_list_append(const StiffList &sl, int64_t p) {
+    const unsigned idx = atomicAdd(sl.count, 1u);
+    sl.particles[idx] = (int32_t)p;
+}
+__global__ void __launch_bounds__(256)
+mm_stiff_scan_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, StiffList sl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sl.count_next = 0u;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && mm_is_stiff(theta[p], theta[stride + p])) stiff_list_append(sl, p);
+}
+
+// ---------------------------------------------------------------------------------------------
 // proposal (Micmem_SMC_main.py:220-228)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -53,6 +79,20 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
         if (mh.zero_counters && threadIdx.x < sizeof(SweepCounters) / 8)
             reinterpret_cast<unsigned long long *>(mh.zero_counters)[threadIdx.x] = 0ull;
         if (mh.zero_queue && threadIdx.x == 64) mh.zero_queue[0] = 0ull;
+        if (mh.stiff.particles && threadIdx.x == 65) *mh.stiff.count_next = 0u;
+        if (mh.reject_out && threadIdx.x == 66) {   // what mm_certainly_rejected reads during the solve of this sweep
+            RejectArgs r;
+            r.lk1 = mh.reject_lk1;
+            r.rr = mh.rr;
+            r.pratio = mh.pratio;
+            r.gamma = mh.gamma;
+            r.seed = mh.seed;
+            r.stream = mh.stream;
+            r.global_offset = mh.global_offset;
+            r.device_rng = mh.device_rng;
+            r.prior_mode = mh.prior_mode;
+            *mh.reject_out = r;
+        }
     }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -95,10 +135,14 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
         mh.pratio[p] = pdf / cur;
     }
     const double p0 = (pdf > 0.0 || mh.prior_mode == SMC_PRIOR_MODE_RATIO) ? 1.0 : 0.0, q0 = 1.0 - p0;
-    prop[p] = __dadd_rn(__dmul_rn(c0, p0), __dmul_rn(f0, q0));
-    prop[pstride + p] = __dadd_rn(__dmul_rn(c1, p0), __dmul_rn(f1, q0));
+    const double w0 = __dadd_rn(__dmul_rn(c0, p0), __dmul_rn(f0, q0)), w1 = __dadd_rn(__dmul_rn(c1, p0), __dmul_rn(f1, q0));
+    prop[p] = w0;
+    prop[pstride + p] = w1;
     prop[2 * pstride + p] = __dadd_rn(__dmul_rn(c2, p0), __dmul_rn(f2, q0));
     p0_out[p] = (uint8_t)(p0 != 0.0);
+    // a proposal inside the support whose solves will be long: onto the list of this sweep (the solve kernel applies the
+    // same predicate to the same stored values when it skips the particle in its index-ordered pass)
+    if (mh.stiff.particles && p0 != 0.0 && mm_is_stiff(w0, w1)) stiff_list_append(mh.stiff, p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -120,7 +164,17 @@ constexpr int kRefillAt = SMC_REFILL_AT;   // idle lanes that make a wave look a
 constexpr int kPoolRefillFree = SMC_POOL_FREE;   // free pool slots that trigger the start of that many new items
 constexpr int kPoolWords = 15;            // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer
 
-struct SolveArgs {
+#ifndef SMC_STIFF_PER_CHUNK
+#define SMC_STIFF_PER_CHUNK 16
+#endif
+// Entries of the stiff list a wave takes with one dequeue.  Fewer than a full wave on purpose: the long solves spread over
+// many waves (12 000 list items of a 10^6-particle prior sweep -> 750 waves), each of which fills its other lanes with
+// ordinary items, so that at the end of the sweep a wave rarely holds two survivors and can run its last one on
+// wave-uniform operands (the tail below).
+constexpr int kStiffPerChunk = SMC_STIFF_PER_CHUNK;
+static_assert(kStiffPerChunk >= 1 && kStiffPerChunk <= 64, "a stiff chunk is started by one wave at once");
+
+struct SolveArgs {              // everything the attempt loops do not touch stays behind a pointer (RejectArgs, StiffList)
     const double *theta;        // SoA rows: Vmax at [p], Km at [stride + p], sigma at [2*stride + p]
     int64_t stride, n;
     const uint8_t *p0;          // MH: support flags; items of particles with p0 == 0 are not solved
@@ -128,14 +182,9 @@ struct SolveArgs {
     int *info;                  // [e*n + p]: attempts | cancelled << 29 | failed << 30
     double *pred;               // optional: P_model, [(p*n_ex + e)*n_t + i]
     unsigned long long *queue;  // global item counter (zeroed before the launch)
-    // Exact early rejection (Metropolis sweeps only; lk1 == nullptr: off).  See mm_certainly_rejected().
-    const double *lk1;          // likelihood of the current particles (lk1, Micmem_SMC_main.py:231)
-    const double *rr;           // host-RNG mode: the uniforms of :235
-    const double *pratio;       // prior_mode != MASK: p0_2 / p0_1
-    double gamma;
-    uint64_t seed, stream;
-    int64_t global_offset;
-    int device_rng, prior_mode;
+    const RejectArgs *rej;      // exact early rejection (Metropolis sweeps only; nullptr: off): see mm_certainly_rejected()
+    const int32_t *stiff_list;  // particles whose solves are handed out first (nullptr: none), and how many
+    const unsigned *stiff_count;
 };
 
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
@@ -183,15 +232,16 @@ __device__ __forceinline__ bool mm_certainly_rejected(const MMModel &mm, const S
         }
         lk2_bound += mm_loglik_term(c0, S, s2);
     }
+    const RejectArgs &r = *a.rej;     // device memory, written by the propose kernel of this sweep
     double rr;
-    if (a.device_rng) {
-        const u32x4 ru = philox_block(a.seed, (uint64_t)(a.global_offset + p), a.stream, SMC_PHILOX_BLOCK_UNIFORM);
+    if (r.device_rng) {
+        const u32x4 ru = philox_block(r.seed, (uint64_t)(r.global_offset + p), r.stream, SMC_PHILOX_BLOCK_UNIFORM);
         rr = u01_from(ru.x, ru.y);
     } else {
-        rr = a.rr[p];
+        rr = r.rr[p];
     }
-    double pp = exp((lk2_bound - a.lk1[p]) * a.gamma);
-    if (a.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * a.pratio[p];
+    double pp = exp((lk2_bound - r.lk1[p]) * r.gamma);
+    if (r.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * r.pratio[p];
     return pp < rr * (1.0 - 1e-12);   // the margin covers a last-bit non-monotonicity of exp
 }
 constexpr int kRejectCheckEvery = 512;   // attempts between two looks at the bound (a look costs about five attempts)
@@ -207,6 +257,11 @@ __device__ __forceinline__ double lane_value(double v, int src) {
 #define SMC_SOLVE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SMC_SOLVE_WAVES, SMC_SOLVE_WAVES)))
 #else
 #define SMC_SOLVE_WAVES_ATTR
+#endif
+#ifdef SMC_ISA_MARKS   // analysis builds only (tools/isa_blocks.py): names the loops in the `hipcc -S` listing
+#define SMC_ISA_MARK(name) asm volatile("; MARK " name)
+#else
+#define SMC_ISA_MARK(name)
 #endif
 template <bool WRITE_PRED>
 __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_kernel(MMModel mm, SolveArgs a) {
@@ -224,9 +279,14 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     // active), and a lane that finishes takes its next item from the pool after at most a few attempts of waiting.
     double *s_pool = s_S0 + ((n_ex + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kPoolWords * kWave);
 
-    // items are laid out in groups of 64 particles x n_ex experiments; the last group may be partial
+    // Queue space: first the stiff list, n_ex passes over it in chunks of kChunk indices of which the first kStiffPerChunk
+    // are list entries (so that the chunk arithmetic below stays in units of kChunk), then the index-ordered items in groups
+    // of 64 particles x n_ex experiments; the last group may be partial.
     const unsigned long long n_blk = (unsigned long long)((a.n + kWave - 1) / kWave);
-    const unsigned long long n_items = n_blk * kWave * n_ex;
+    const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)*a.stiff_count) : 0u;
+    const unsigned stiff_cpe = (n_stiff + kStiffPerChunk - 1) / kStiffPerChunk;          // chunks per experiment
+    const unsigned long long q_stiff_end = (unsigned long long)stiff_cpe * n_ex * kChunk;
+    const unsigned long long n_items = q_stiff_end + n_blk * kWave * n_ex;
     const int lane = threadIdx.x & (kWave - 1);
     const double rtol = mm.rtol, atol = mm.atol;
 
@@ -241,9 +301,11 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     // bookkeeping: 0.19 us per iteration on top of the 0.41 us of an attempt for a wave that runs alone (the stragglers of
     // the early tempering steps), measured with tools/tail_latency.py.
     unsigned long long q_lo = 0, q_hi = 0;  // the wave's current chunk
-    unsigned long long q_grp = 0;           // 64-item group of the chunk's first item, and that group's ...
-    unsigned long long q_blk = 0;           // ... block of 64 particles
-    int q_e = 0;                            // ... and experiment (one 64-bit division per chunk, none per hand-out)
+    unsigned long long q_blk = 0;           // regular chunk: block of 64 particles of the 64-item group of its first item ...
+    unsigned long long q_grp = 0;           // ... that group
+    int q_e = 0;                            // ... and experiment (one division per chunk, none per hand-out)
+    unsigned q_list = 0;                    // stiff chunk: list index of its first entry
+    bool q_stiff = false;
     bool drained = false;                   // the global queue is empty
 
     int pool_head = 0, pool_count = 0;      // the ring of started items: slots [head, head + count) mod 64 (wave-uniform)
@@ -251,24 +313,33 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     for (;;) {
         // ---- start new items into the pool ------------------------------------------------------------------
         if (!drained && kWave - pool_count >= kPoolRefillFree) {
-            if (q_lo == q_hi) {  // next chunk: one atomic per wave and kChunk items
-                // No `if (lane == 0)` around the atomic: the compiler may split such a branch from the v_readfirstlane
-                // that follows it and let the other lanes run ahead with b = 0 (profiles/r02_k8_dequeue_hang_isa.md has
-                // two cases).  Every lane adds kChunk / 64, a wave-uniform operand, so the atomic optimiser issues one
-                // memory atomic of popcount x value and the first lane's return value is the start of the chunk.
-                const unsigned long long b = atomicAdd(a.queue, (unsigned long long)(kChunk / kWave));
+            if (q_lo == q_hi) {  // next chunk: one atomic per wave and kChunk indices
+                // The first active lane adds kChunk, every other lane adds 0, and the first lane's return value is the
+                // start of the chunk: correct whether the compiler's atomic optimiser folds the 64 lane atomics into
+                // one (it does) or not - round 2's form (every lane adds kChunk / 64) was correct only with it.  And no
+                // `if (lane == 0)` around the atomic: the compiler may split such a branch from the v_readfirstlane
+                // that follows it and let the other lanes run ahead with b = 0 (profiles/r02_k8_dequeue_hang_isa.md).
+                const unsigned long long b = atomicAdd(a.queue, lane == 0 ? (unsigned long long)kChunk : 0ull);
                 const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
                 const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
                 q_lo = ((unsigned long long)b_hi << 32) | b_lo;
-                const unsigned long long got = (unsigned long long)__popcll(__builtin_amdgcn_read_exec()) * (kChunk / kWave);
-                q_hi = (q_lo + got < n_items) ? q_lo + got : n_items;
                 if (q_lo >= n_items) {
                     drained = true;
                     q_lo = q_hi = 0;
+                } else if (q_lo < q_stiff_end) {
+                    q_stiff = true;
+                    const unsigned c = (unsigned)(q_lo / kChunk);
+                    q_e = (int)(c / stiff_cpe);
+                    q_list = (c - (unsigned)q_e * stiff_cpe) * kStiffPerChunk;
+                    const unsigned left = n_stiff - q_list;
+                    q_hi = q_lo + (left < (unsigned)kStiffPerChunk ? left : (unsigned)kStiffPerChunk);
+                } else {
+                    q_stiff = false;
+                    q_hi = (q_lo + kChunk < n_items) ? q_lo + kChunk : n_items;
+                    q_grp = (q_lo - q_stiff_end) >> 6;
+                    q_e = (int)(q_grp / n_blk);          // experiment-major: see the item order note above
+                    q_blk = q_grp - (unsigned long long)q_e * n_blk;
                 }
-                q_grp = q_lo >> 6;
-                q_e = (int)(q_grp / n_blk);          // experiment-major: see the item order note above
-                q_blk = q_grp - (unsigned long long)q_e * n_blk;
             }
             if (!drained) {
                 const unsigned long long avail = q_hi - q_lo;
@@ -279,22 +350,29 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
                 int64_t nb_idx = 0;
                 double *nb_pred = nullptr;
                 if (lane < take) {
-                    const unsigned long long item = q_lo + lane;
-                    // 64-item group = (experiment, block of 64 particles); a chunk spans kChunk / 64 + 1 groups at most
-                    unsigned long long blk = q_blk + ((item >> 6) - q_grp);
+                    int64_t p;
                     int e = q_e;
+                    if (q_stiff) {
+                        p = a.stiff_list[q_list + (unsigned)(q_lo % kChunk) + (unsigned)lane];
+                    } else {
+                        const unsigned long long item = q_lo - q_stiff_end + lane;
+                        // 64-item group = (experiment, block of 64 particles); a chunk spans kChunk / 64 + 1 groups at most
+                        unsigned long long blk = q_blk + ((item >> 6) - q_grp);
 #pragma unroll
-                    for (int w = 0; w < kChunk / 64 + 1; ++w)
-                        if (blk >= n_blk) { blk -= n_blk; ++e; }
-                    const int64_t p = (int64_t)blk * kWave + (int64_t)(item & 63);
+                        for (int w = 0; w < kChunk / 64 + 1; ++w)
+                            if (blk >= n_blk) { blk -= n_blk; ++e; }
+                        p = (int64_t)blk * kWave + (int64_t)(item & 63);
+                    }
                     if (p < a.n) {
                         nb_idx = (int64_t)e * a.n + p;
-                        bool run = true;
-                        if (a.p0 && a.p0[p] == 0) run = false;          // masked proposal: lk2 == lk1, no solve
+                        const bool masked = a.p0 && a.p0[p] == 0;        // masked proposal: lk2 == lk1, no solve
                         const double Vmax = a.theta[p], Km = a.theta[a.stride + p];
                         const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
-                        if (sigma <= 0.0) run = false;                   // -inf without solving (:53-54)
-                        if (run) {
+                        // index-ordered pass: a particle of the stiff list has been handed out already
+                        const bool listed = !q_stiff && a.stiff_list && !masked && mm_is_stiff(Vmax, Km);
+                        const bool run = !masked && !(sigma <= 0.0);     // sigma <= 0: -inf without solving (:53-54)
+                        if (listed) {
+                        } else if (run) {
                             if (WRITE_PRED) nb_pred = a.pred + ((size_t)p * n_ex + e) * n_t;
                             started = mm_item_begin<WRITE_PRED>(nb, Vmax, Km, s_S0[e], s_tp, mm_table_row(e, n_t), n_t, rtol,
                                                                 atol, nb_pred);
@@ -419,33 +497,44 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
                     int st = 0;
                     bool cancelled = false;
                     for (;;) {
-                        if (a.lk1 && mm_certainly_rejected(mm, a, u_p, u_e, u.sum_r2)) {   // first look at once
+                        // first look at once.  Every lane evaluates the same bound on the same operands, but its atomic
+                        // loads are a source of divergence for the compiler: without the v_readfirstlane it wraps the
+                        // WHOLE attempt loop below in exec-mask control flow (s_and_saveexec per branch, per-lane selects)
+                        // instead of scalar branches - that is how the uniform tail lost a tenth of a microsecond per
+                        // attempt when early rejection went in (tools/isa_blocks.py on the listing: 11 saveexec / 0
+                        // s_cbranch_vcc with the bare call, 0 / 8 with the broadcast).
+                        if (a.rej && __builtin_amdgcn_readfirstlane((int)mm_certainly_rejected(mm, a, u_p, u_e, u.sum_r2))) {
                             cancelled = true;
                             break;
                         }
                         int budget = kRejectCheckEvery;
                         do {
+                            SMC_ISA_MARK("uniform_tail_attempt");
                             st = mm_item_attempt<WRITE_PRED>(u, s_tp, n_t, rtol, atol, u_pred);
                         } while (st == 0 && --budget > 0);
                         if (st != 0) break;
                     }
-                    if (lane == src) {
-                        if (cancelled) {
-                            publish_item(a, out_idx, kSumCancelled, u.attempts | kInfoCancelled);
-                        } else {
-                            const bool ok = (st == 1) && (u.i_out == n_t);
-                            publish_item(a, out_idx, ok ? u.sum_r2 : quiet_nan(), u.attempts | (ok ? 0 : kInfoFailed));
-                            if (WRITE_PRED && !ok)
-                                for (int i = u.i_out; i < n_t; ++i) u_pred[i] = quiet_nan();
-                        }
+                    // Every lane holds the same result and stores it to the same address (u_idx is a scalar): one wave-wide
+                    // store of 64 identical values instead of an `if (lane == src)` - a divergent branch whose join would
+                    // be this loop's exit block, which is exactly what makes the compiler's uniformity analysis call the
+                    // whole tail loop, with its ballots and v_readlanes, a cycle with a divergent exit
+                    // (tests/test_k8_uniform_control.py checks that it does not).
+                    if (cancelled) {
+                        publish_item(a, u_idx, kSumCancelled, u.attempts | kInfoCancelled);
+                    } else {
+                        const bool ok = (st == 1) && (u.i_out == n_t);
+                        publish_item(a, u_idx, ok ? u.sum_r2 : quiet_nan(), u.attempts | (ok ? 0 : kInfoFailed));
+                        if (WRITE_PRED && !ok)
+                            for (int i = u.i_out; i < n_t; ++i) u_pred[i] = quiet_nan();
                     }
+                    live = false;
                     break;
                 }
                 // several stiff items in this wave: per-lane attempts until one of them is done, then look again
                 int n_now, since_check = kRejectCheckEvery;     // first look at the bound at once
                 do {
                     if (live) {
-                        if (a.lk1 && ++since_check > kRejectCheckEvery) {
+                        if (a.rej && ++since_check > kRejectCheckEvery) {
                             since_check = 0;
                             const int e_self = (int)(out_idx / a.n);
                             if (mm_certainly_rejected(mm, a, out_idx - (int64_t)e_self * a.n, e_self, it.sum_r2)) {
@@ -455,6 +544,7 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
                         }
                     }
                     if (live) {
+                        SMC_ISA_MARK("lane_tail_attempt");
                         const int st = mm_item_attempt<WRITE_PRED>(it, s_tp, n_t, rtol, atol, pred_item);
                         if (st != 0) {
                             const bool ok = (st == 1) && (it.i_out == n_t);
@@ -474,6 +564,7 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
         // per attempt) - the scheduling logic above runs once per hand-out, not once per attempt
         int idle_now;
         do {
+            SMC_ISA_MARK("bulk_attempt");
             if (live) {
                 const int st = mm_item_attempt<WRITE_PRED>(it, s_tp, n_t, rtol, atol, pred_item);
                 if (st != 0) {
@@ -630,8 +721,19 @@ static size_t solve_lds_bytes(int n_ex, int n_t) {
            (size_t)(kSolveBlock / kWave) * kPoolWords * kWave * sizeof(double);
 }
 
+// The stiff list of the next sweep: its counter, and the other one for the kernel that builds the list to clear.
+static StiffList next_stiff_list(smc_ctx *ctx) {
+    StiffList sl{};
+    if (!ctx->stiff_first || !ctx->d_stiff_list) return sl;
+    ctx->stiff_parity ^= 1;
+    sl.particles = ctx->d_stiff_list;
+    sl.count = ctx->d_stiff_count + ctx->stiff_parity;
+    sl.count_next = ctx->d_stiff_count + (ctx->stiff_parity ^ 1);
+    return sl;
+}
+
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
-                         bool queue_cleared = false, const MHParams *mh_reject = nullptr) {
+                         const StiffList &sl, bool queue_cleared = false, bool reject = false) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
     a.theta = theta;
@@ -642,30 +744,27 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.info = ctx->d_info;
     a.pred = pred;
     a.queue = ctx->d_queue;
-    if (mh_reject) {
-        a.lk1 = ctx->set[SMC_SET_FILT].lk;
-        a.rr = mh_reject->rr;
-        a.pratio = mh_reject->pratio;
-        a.gamma = mh_reject->gamma;
-        a.seed = mh_reject->seed;
-        a.stream = mh_reject->stream;
-        a.global_offset = mh_reject->global_offset;
-        a.device_rng = mh_reject->device_rng;
-        a.prior_mode = mh_reject->prior_mode;
-    }
+    a.rej = reject ? ctx->d_reject : nullptr;
+    a.stiff_list = sl.particles;
+    a.stiff_count = sl.count;
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
-    if (lds > 48 * 1024) {   // the largest data set (16 x 256) needs 66 + 30 KB of the CU's 160 KB: above the default dynamic limit
-        static bool raised = false;
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            raised = true;
+    if (lds > 48 * 1024 && !ctx->solve_lds_raised) {
+        // the largest data set (16 x 256) needs 66 + 30 KB of the CU's 160 KB: above the default dynamic limit.  The
+        // attribute belongs to the (function, device) pair, so the flag lives in the context, not in the process.
+        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            smc_fail(ctx, "mm_solve_kernel: raising the dynamic LDS limit failed (hipFuncSetAttribute)");
+            ctx->launch_failed = true;
+            return;
         }
+        ctx->solve_lds_raised = true;
     }
-    // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more blocks than chunks
+    // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more blocks than chunks (the chunks
+    // of the stiff list are extra; how many is only known on the device, the waves simply go on until the queue is empty)
     const int64_t chunks = (((n + kWave - 1) / kWave) * kWave * mm.n_ex + kChunk - 1) / kChunk;
     int64_t blocks = (int64_t)ctx->cu_count * ctx->solve_blocks_per_cu;
     const int64_t need = (chunks + (kSolveBlock / kWave) - 1) / (kSolveBlock / kWave);
@@ -680,7 +779,10 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
 
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred) {
     if (n <= 0) return;
-    launch_solve(ctx, theta, stride, n, nullptr, pred);
+    const StiffList sl = next_stiff_list(ctx);
+    if (sl.particles)
+        hipLaunchKernelGGL(mm_stiff_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, theta, stride, n, sl);
+    launch_solve(ctx, theta, stride, n, nullptr, pred, sl);
     MHParams mh{};
     hipLaunchKernelGGL((mm_finish_kernel<0>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        theta, stride, n, ctx->d_sum_r2, ctx->d_info, nullptr, lk, nullptr, 0, nullptr, ctx->d_counters,
@@ -693,15 +795,18 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     ParticleSet &P = ctx->set[SMC_SET_PRED];  // receives the proposals, as the reference's p_pred does (:220,228)
     const bool dbg = ctx->debug_capture != 0;
     // exact early rejection: off while the proposals' likelihoods are captured for inspection (they would be incomplete)
-    const bool reject = ctx->early_reject != 0 && !dbg && mh_in.gamma > 0.0;
+    const bool reject = ctx->early_reject != 0 && !dbg && mh_in.gamma > 0.0 && ctx->d_reject;
     MHParams mh = mh_in;
     if (reject) {
         mh.pending_sums = ctx->d_sum_r2;
         mh.pending_n_ex = ctx->mm.n_ex;
+        mh.reject_out = ctx->d_reject;
+        mh.reject_lk1 = F.lk;
     }
+    mh.stiff = next_stiff_list(ctx);
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
-    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.zero_queue != nullptr, reject ? &mh : nullptr);
+    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.stiff, mh.zero_queue != nullptr, reject);
     ctx->moment_rows_n = mh.moment_rows ? (int)finish_grid(n) : 0;
     hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        P.theta, P.stride, n, ctx->d_sum_r2, ctx->d_info, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac,
@@ -711,7 +816,7 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
 int query_solve_blocks_per_cu() {
     if (const char *e = getenv("SMC_SOLVE_BLOCKS_PER_CU")) {   // experiments: persistent blocks (4 waves each) per CU
         const int v = atoi(e);
-        if (v >= 1) return v;
+        if (v >= 1) return v < 16 ? v : 16;     // beyond the hardware's wave slots the extra blocks only queue up
     }
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false>, kSolveBlock, solve_lds_bytes(6, 40)) != hipSuccess || nb < 1)

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 
+#include "exchange_plan.h"
 #include "smc_internal.h"
 #include "stage_kernels.h"
 
@@ -136,6 +137,9 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMemsetAsync(c->r_ac, 0, (size_t)n_local, c->stream));
     CK(hipMalloc(&c->d_counters, sizeof(SweepCounters)));
     CK(hipMalloc(&c->d_queue, 2 * sizeof(unsigned long long)));
+    CK(hipMalloc(&c->d_reject, sizeof(RejectArgs)));
+    CK(hipMalloc(&c->d_stiff_count, 2 * sizeof(unsigned)));
+    CK(hipMemsetAsync(c->d_stiff_count, 0, 2 * sizeof(unsigned), c->stream));
     CK(hipMalloc(&c->d_p0, (size_t)n_local));
     {
         hipDeviceProp_t prop;
@@ -150,6 +154,9 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     c->partials_cap = 2048 * 64;
     CK(hipMalloc(&c->d_partials, (size_t)c->partials_cap * sizeof(double)));
     CK(hipMalloc(&c->d_small, 4096 * sizeof(double)));
+    CK(hipMalloc(&c->d_fused, 256 * sizeof(double)));
+    CK(hipMemsetAsync(c->d_fused, 0, 256 * sizeof(double), c->stream));
+    CK(hipHostMalloc(&c->h_fused, 256 * sizeof(double)));
     CK(hipHostMalloc(&c->h_small, 4096 * sizeof(double)));
     c->n_tiles = (n_local + kScanTile - 1) / kScanTile;
     CK(hipMalloc(&c->d_oscan, (size_t)n_local * sizeof(int32_t)));
@@ -188,6 +195,8 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_stage);
     (void)hipFree(c->d_partials);
     (void)hipFree(c->d_small);
+    (void)hipFree(c->d_fused);
+    if (c->h_fused) (void)hipHostFree(c->h_fused);
     if (c->h_small) (void)hipHostFree(c->h_small);
     (void)hipFree(c->d_oscan);
     (void)hipFree(c->d_blk_r);
@@ -204,6 +213,9 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_mn_thr);
     (void)hipFree(c->d_mn_blk);
     (void)hipFree(c->d_queue);
+    (void)hipFree(c->d_reject);
+    (void)hipFree(c->d_stiff_count);
+    (void)hipFree(c->d_stiff_list);
     (void)hipFree(c->d_mcond);
     (void)hipFree(c->d_mguess);
     (void)hipFree(c->d_mobs);
@@ -374,6 +386,12 @@ int smc_set_early_reject(smc_ctx *c, int enable) {
     return 0;
 }
 
+int smc_set_stiff_first(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    c->stiff_first = enable != 0;
+    return 0;
+}
+
 int smc_set_resampling(smc_ctx *c, int scheme) {
     if (!c) return fail(nullptr, "NULL context");
     if (scheme != SMC_RESAMPLE_RESIDUAL_SYSTEMATIC && scheme != SMC_RESAMPLE_SYSTEMATIC && scheme != SMC_RESAMPLE_MULTINOMIAL)
@@ -464,11 +482,15 @@ static int ensure_item_capacity(smc_ctx *c, int64_t n) {
     HIPC(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_sum_r2);
     (void)hipFree(c->d_info);
+    (void)hipFree(c->d_stiff_list);
     c->d_sum_r2 = nullptr;
     c->d_info = nullptr;
+    c->d_stiff_list = nullptr;
     c->item_cap = 0;
     HIPC(c, hipMalloc(&c->d_sum_r2, (size_t)n * c->mm.n_ex * sizeof(double)));
     HIPC(c, hipMalloc(&c->d_info, (size_t)n * c->mm.n_ex * sizeof(int)));
+    HIPC(c, hipMalloc(&c->d_stiff_list, (size_t)n * sizeof(int32_t)));   // every particle at most once per sweep
+    HIPC(c, hipMemsetAsync(c->d_stiff_count, 0, 2 * sizeof(unsigned), c->stream));
     c->item_cap = n;
     return 0;
 }
@@ -825,6 +847,26 @@ int smc_debug_rccl_self_exchange(smc_ctx *c, int64_t row, int64_t cnt, int64_t d
     return 0;
 }
 
+int smc_exchange_plan(int world, int rank, int64_t n_local, const int64_t *out_base_all, const int64_t *offspring_all,
+                      int64_t *send_off, int64_t *send_cnt, int64_t *src_lo, int64_t *recv_off, int64_t *recv_cnt,
+                      int64_t *recv_row, int64_t *own /* src_lo, cnt, row */, int64_t *stale_lo) {
+    if (world < 1 || world > SMC_MAX_RANKS || rank < 0 || rank >= world || n_local < 1 || !out_base_all || !offspring_all)
+        return 2;
+    const ExchangePlan p = make_exchange_plan(world, rank, n_local, out_base_all, offspring_all);
+    if (!p.prefix_ok) return 1;
+    for (int q = 0; q < world; ++q) {
+        if (send_off) send_off[q] = p.send_off[q];
+        if (send_cnt) send_cnt[q] = p.send_cnt[q];
+        if (src_lo) src_lo[q] = p.src_lo[q];
+        if (recv_off) recv_off[q] = p.recv_off[q];
+        if (recv_cnt) recv_cnt[q] = p.recv_cnt[q];
+        if (recv_row) recv_row[q] = p.recv_row[q];
+    }
+    if (own) { own[0] = p.own_src_lo; own[1] = p.own_cnt; own[2] = p.own_row; }
+    if (stale_lo) *stale_lo = p.stale_lo;
+    return 0;
+}
+
 int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *offspring_all, int first_step) {
     if (!c) return fail(nullptr, "NULL context");
     HIPC(c, hipSetDevice(c->device));
@@ -832,59 +874,37 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
     const int W = c->world, R = c->rank, d = c->dim;
     const int64_t nl = c->n_local;
     ParticleSet &F = c->set[SMC_SET_FILT];
-    int64_t total = 0;
-    for (int q = 0; q < W; ++q) {
-        if (out_base_all[q] != total) return fail(c, "out_base_all must be the exclusive prefix of offspring_all");
-        total += offspring_all[q];
-    }
-    if (total > c->n_global)
+    const ExchangePlan plan = make_exchange_plan(W, R, nl, out_base_all, offspring_all);   // exchange_plan.h
+    if (!plan.prefix_ok) return fail(c, "out_base_all must be the exclusive prefix of offspring_all");
+    if (plan.total > c->n_global)
         return fail(c, "resampling produced more offspring than particles (the reference raises IndexError, "
                        "Micmem_SMC_main.py:180)");
-    const int64_t my_base = out_base_all[R], my_cnt = offspring_all[R];
     ScopedTimer tm(c, SMC_T_RESAMPLE);
 
-    // how much leaves this rank
-    int64_t remote = 0;
-    for (int q = 0; q < W; ++q) {
-        if (q == R) continue;
-        const int64_t lo = imax(my_base, q * nl), hi = imin(my_base + my_cnt, (q + 1) * nl);
-        if (hi > lo) remote += hi - lo;
-    }
-    if (remote > c->sendbuf_cap) {
+    if (plan.send_total > c->sendbuf_cap) {   // how much leaves this rank
         HIPC(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_sendbuf);
         c->d_sendbuf = nullptr;
         c->sendbuf_cap = 0;
-        HIPC(c, hipMalloc(&c->d_sendbuf, (size_t)remote * (d + 1) * sizeof(double)));
-        c->sendbuf_cap = remote;
+        HIPC(c, hipMalloc(&c->d_sendbuf, (size_t)plan.send_total * (d + 1) * sizeof(double)));
+        c->sendbuf_cap = plan.send_total;
     }
     if (W > 1 && !c->nccl_comm && c->peers.empty()) return fail(c, "world > 1 but smc_comm_init has not been called");
 
     // 1. gather: own slots straight into p_filt / lk1, remote slots into the send staging
-    int64_t soff = 0;
-    std::vector<int64_t> send_off(W, 0), send_cnt(W, 0);
+    if (plan.own_cnt > 0)
+        launch_resample_gather(c, plan.own_src_lo, plan.own_src_lo + plan.own_cnt, F.theta, F.stride, F.lk, plan.own_row);
     for (int q = 0; q < W; ++q) {
-        const int64_t lo = imax(my_base, q * nl), hi = imin(my_base + my_cnt, (q + 1) * nl);
-        if (hi <= lo) continue;
-        if (q == R) {
-            launch_resample_gather(c, lo - my_base, hi - my_base, F.theta, F.stride, F.lk, lo - R * nl);
-        } else {
-            const int64_t cnt = hi - lo;
-            double *blk = c->d_sendbuf + (size_t)soff * (d + 1);  // [component][cnt], component d = lk
-            launch_resample_gather(c, lo - my_base, hi - my_base, blk, cnt, blk + (size_t)d * cnt, 0);
-            send_off[q] = soff;
-            send_cnt[q] = cnt;
-            soff += cnt;
-        }
+        const int64_t cnt = plan.send_cnt[q];
+        if (cnt <= 0) continue;
+        double *blk = c->d_sendbuf + (size_t)plan.send_off[q] * (d + 1);  // [component][cnt], component d = lk
+        launch_resample_gather(c, plan.src_lo[q], plan.src_lo[q] + cnt, blk, cnt, blk + (size_t)d * cnt, 0);
     }
     // 2. rows nobody writes (total < N): what the reference's persistent buffers hold
-    {
-        const int64_t lo = imax(total - R * nl, 0);
-        if (lo < nl) launch_resample_stale(c, lo, nl, first_step);
-    }
+    if (plan.stale_lo < nl) launch_resample_stale(c, plan.stale_lo, nl, first_step);
     HIPC(c, hipGetLastError());
-    c->plan_send_off = send_off;
-    c->plan_send_cnt = send_cnt;
+    c->plan_send_off = plan.send_off;
+    c->plan_send_cnt = plan.send_cnt;
     c->plan_base.assign(out_base_all, out_base_all + W);
     c->plan_cnt.assign(offspring_all, offspring_all + W);
     if (W > 1 && !c->peers.empty()) {  // loopback rehearsal: the pull happens after a barrier between the ranks
@@ -893,20 +913,8 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
     }
     // 3. exchange: ONE contiguous send and ONE contiguous recv per peer ([component][cnt] blocks), then the
     //    received blocks are spread over the SoA rows by device-to-device row copies on the same stream
-    if (W > 1) {
-        std::vector<int64_t> recv_off(W, 0), recv_cnt(W, 0), recv_row(W, 0);
-        int64_t roff = 0;
-        for (int q = 0; q < W; ++q) {
-            if (q == R) continue;
-            const int64_t lo = imax(out_base_all[q], R * nl), hi = imin(out_base_all[q] + offspring_all[q], (R + 1) * nl);
-            if (hi <= lo) continue;
-            recv_off[q] = roff;
-            recv_cnt[q] = hi - lo;
-            recv_row[q] = lo - R * nl;
-            roff += hi - lo;
-        }
-        return rccl_exchange_blocks(c, send_off, send_cnt, recv_off, recv_cnt, recv_row, roff);
-    }
+    if (W > 1)
+        return rccl_exchange_blocks(c, plan.send_off, plan.send_cnt, plan.recv_off, plan.recv_cnt, plan.recv_row, plan.recv_total);
     return 0;
 }
 
@@ -1043,7 +1051,12 @@ int smc_mh_step_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const 
     return mh_finish(c, accepted_now, accepted_ever, n_failed, rk_attempts);
 }
 
-// d_small layout of the fused iteration (doubles): what one read-back of kFusedWords words brings to the host
+// Layout of the fused iteration's own buffer d_fused / h_fused (doubles): what one read-back of kFusedWords words brings to
+// the host.  NOT d_small: the moments an accept kernel leaves at kV are carried to the NEXT iteration (moments_valid), and
+// every other entry point that returns small results (smc_max_lk_*, smc_ess_partials*, smc_moment_*_local, the generic
+// all-reduce / all-gather helpers) writes d_small[0..] - a caller that interleaved one of them between two fused
+// iterations used to get a proposal covariance built from whatever that call left there (now tested:
+// test_fused_iterations_survive_interleaved_small_result_calls).
 constexpr int kV = 0;        // [sum y (d) | sum y y^T (d(d+1)/2) | accepted_now, accepted_ever, n_failed]: ONE all-reduce
 constexpr int kSums = 64;    // two-pass start of a step: column sums, then
 constexpr int kCent = 72;    //   sums centred about the global mean
@@ -1054,7 +1067,7 @@ constexpr int kFusedWords = 256;
 
 static int two_pass_factor(smc_ctx *c, const double *w_cov) {
     const int d = c->dim, npair = d * (d + 1) / 2;
-    double *S = c->d_small;
+    double *S = c->d_fused;
     ScopedTimer tm(c, SMC_T_MOMENTS);
     launch_moment_sums(c, S + kSums);
     if (dev_allreduce(c, S + kSums, (size_t)d, ncclDouble, ncclSum)) return 1;
@@ -1080,7 +1093,7 @@ int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, c
     HIPC(c, hipSetDevice(c->device));
     const int d = c->dim;
     const bool mm = c->model_kind == 1;
-    double *S = c->d_small;
+    double *S = c->d_fused;
     if (mm && c->moments_valid) {
         ScopedTimer tm(c, SMC_T_MOMENTS);
         launch_mh_transform(c, S + kV, nullptr, w_cov, S + kShift, S + kCov, S + kXf);
@@ -1115,15 +1128,15 @@ int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, c
     const int nv = mm ? d + d * (d + 1) / 2 : 0;
     launch_moments_reduce(c, mm ? c->moment_rows_n : 0, nv, S + kV);
     if (dev_allreduce(c, S + kV, (size_t)nv + 3, ncclDouble, ncclSum)) return 1;
-    HIPC(c, hipMemcpyAsync(c->h_small, S, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_fused, S, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (counters_end(c)) return 1;      // this rank's counters + the one synchronisation of the iteration
     c->moments_valid = mm;
-    if (accepted_now) *accepted_now = (int64_t)c->h_small[kV + nv];
-    if (accepted_ever) *accepted_ever = (int64_t)c->h_small[kV + nv + 1];
-    if (n_failed) *n_failed = (int64_t)c->h_small[kV + nv + 2];
+    if (accepted_now) *accepted_now = (int64_t)c->h_fused[kV + nv];
+    if (accepted_ever) *accepted_ever = (int64_t)c->h_fused[kV + nv + 1];
+    if (n_failed) *n_failed = (int64_t)c->h_fused[kV + nv + 2];
     if (rk_attempts_local) *rk_attempts_local = (int64_t)c->h_counters->rk_attempts;
     if (cov_m)
-        for (int i = 0; i < d * d; ++i) cov_m[i] = c->h_small[kCov + i];
+        for (int i = 0; i < d * d; ++i) cov_m[i] = c->h_fused[kCov + i];
     return 0;
 }
 
@@ -1137,11 +1150,11 @@ int smc_proposal_factor_device(smc_ctx *c, const double *w_cov, double *cov_m, d
     c->moments_valid = false;
     if (two_pass_factor(c, w_cov)) return 1;
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(c->h_small, c->d_small, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_fused, c->d_fused, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < d * d; ++i) {
-        if (cov_m) cov_m[i] = c->h_small[kCov + i];
-        if (transform) transform[i] = c->h_small[kXf + i];
+        if (cov_m) cov_m[i] = c->h_fused[kCov + i];
+        if (transform) transform[i] = c->h_fused[kXf + i];
     }
     return 0;
 }
@@ -1149,7 +1162,7 @@ int smc_proposal_factor_device(smc_ctx *c, const double *w_cov, double *cov_m, d
 // the d x d factor the last smc_mh_iteration_device_rng drew its proposals with (row-major; debugging / tests)
 int smc_mh_iteration_last_transform(smc_ctx *c, double *transform) {
     if (!c) return fail(nullptr, "NULL context");
-    for (int i = 0; i < c->dim * c->dim; ++i) transform[i] = c->h_small[kXf + i];
+    for (int i = 0; i < c->dim * c->dim; ++i) transform[i] = c->h_fused[kXf + i];
     return 0;
 }
 

@@ -51,6 +51,30 @@ struct ParticleSet {  // SoA view: theta[c][i] = theta_base[c*stride + i]
 };
 
 struct SweepCounters;
+
+// What the exact early-rejection bound of the solve kernel needs (mm_kernels.hip: mm_certainly_rejected).  Lives in DEVICE
+// memory (ctx->d_reject) and is written by the propose kernel of the sweep, so that the solve kernel carries one pointer
+// instead of nine kernel arguments in scalar registers through its attempt loops (144 SGPR spills).
+struct RejectArgs {
+    const double *lk1;          // likelihood of the current particles (lk1, Micmem_SMC_main.py:231)
+    const double *rr;           // host-RNG mode: the uniforms of :235
+    const double *pratio;       // prior_mode != MASK: p0_2 / p0_1
+    double gamma;
+    uint64_t seed, stream;
+    int64_t global_offset;
+    int device_rng, prior_mode;
+};
+
+// The list of predictably long solves ("stiff list") of a sweep: particles with Vmax > kStiffRatio * Km.  Built by the
+// propose kernel (Metropolis sweeps) or by mm_stiff_scan_kernel (likelihood sweeps), handed out by the solve kernel BEFORE
+// the index-ordered items so that the serial chains that bound a sweep start at its very beginning.  Two counters used
+// alternately: the kernel that builds the list of sweep k clears the counter of sweep k + 1.
+struct StiffList {
+    int32_t *particles;         // capacity = item_cap (every particle at most once per sweep)
+    unsigned *count;            // the counter of THIS sweep
+    unsigned *count_next;       // the other one: cleared while this sweep's list is built
+};
+
 struct MHParams {    // passed by value to the fused MH kernel
     double gamma, ratio;
     const double *noise;  // host-RNG mode: SoA d x n (device); nullptr in device-RNG mode
@@ -72,6 +96,10 @@ struct MHParams {    // passed by value to the fused MH kernel
     int device_rng;
     int prior_mode;       // SMC_PRIOR_MODE_*
     double *pratio;       // prior_mode != MASK: p0_2 / p0_1 per particle (written by propose, read by accept)
+    // Michaelis-Menten path: the propose kernel also publishes the early-rejection arguments and builds the stiff list
+    RejectArgs *reject_out;     // nullptr: early rejection off in this sweep
+    const double *reject_lk1;
+    StiffList stiff;            // particles == nullptr: no list
 };
 
 struct SweepCounters {  // device-side integer counters (order-independent atomics)
@@ -122,6 +150,7 @@ struct smc_ctx {
     double *d_partials = nullptr;                // reduction partials
     int64_t partials_cap = 0;
     double *d_small = nullptr, *h_small = nullptr;  // small results (device / pinned host), 4096 doubles
+    double *d_fused = nullptr, *h_fused = nullptr;  // the fused Metropolis iteration's own 256 doubles (carried moments, cov_m, factor)
     // resampling
     int32_t *d_oscan = nullptr;      // inclusive offspring scan (n_local)
     double *d_blk_r = nullptr;       // per tile: residual sums, then exclusive prefix
@@ -144,6 +173,12 @@ struct smc_ctx {
     double *d_mn_thr = nullptr;      // multinomial resampling: n_global + 1 thresholds
     double *d_mn_blk = nullptr;      // ... and their per-tile sums
     unsigned long long *d_queue = nullptr;
+    smc::RejectArgs *d_reject = nullptr;   // early-rejection arguments of the running sweep (written by its propose kernel)
+    int32_t *d_stiff_list = nullptr;       // stiff list (item_cap entries) and its two alternating counters
+    unsigned *d_stiff_count = nullptr;
+    int stiff_parity = 0;
+    int stiff_first = 1;                   // hand the predictably long solves out first (smc_set_stiff_first)
+    bool solve_lds_raised = false;         // hipFuncAttributeMaxDynamicSharedMemorySize raised on THIS device
     int cu_count = 0, solve_blocks_per_cu = 0;
     // debug capture of the last MH iteration (lk2, accept flags; proposals live in SMC_SET_PRED)
     int debug_capture = 0;
@@ -152,7 +187,7 @@ struct smc_ctx {
     // host batch sweeps (drop-in sim_particle)
     double *d_hb_theta = nullptr, *d_hb_lk = nullptr, *d_hb_pred = nullptr;
     int64_t hb_cap = 0, hb_pred_cap = 0;
-    // fused Metropolis iterations: d_small holds the moments of the FILT set that the last accept kernel accumulated (valid
+    // fused Metropolis iterations: d_fused holds the moments of the FILT set that the last accept kernel accumulated (valid
     // until anything else writes the FILT set)
     bool moments_valid = false;
     int moment_rows_n = 0;           // per-block partial rows the last accept kernel wrote to d_partials

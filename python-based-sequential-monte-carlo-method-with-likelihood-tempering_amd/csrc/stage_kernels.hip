@@ -655,7 +655,13 @@ __global__ void resample_stale_rows_kernel(const double *__restrict__ src_theta,
 // 128 .. 4096 with the transposing wave reduction in place: profiles/r02_ess_bench.log; more blocks mean more rows for the
 // final sum, fewer leave SIMDs idle)
 static inline int reduce_grid(int64_t n, int cap = 2048) {
-    static const int ess_cap = getenv("SMC_REDUCE_BLOCKS") ? atoi(getenv("SMC_REDUCE_BLOCKS")) : 512;
+    // A/B knob, clamped: the ESS pass writes 2 K <= 32 partial rows per block into d_partials (2048 * 64 doubles), so
+    // anything above 4096 blocks would run over its end
+    static const int ess_cap = [] {
+        const char *e = getenv("SMC_REDUCE_BLOCKS");
+        const int v = e ? atoi(e) : 512;
+        return v < 1 ? 1 : (v > 4096 ? 4096 : v);
+    }();
     if (cap == 512) cap = ess_cap;
     int64_t g = (n + kScanBlock - 1) / kScanBlock;
     if (g > cap) g = cap;    // grid-stride the rest

@@ -60,6 +60,7 @@ class SMCSettings:
     ess_search: str = "backoff"       # the reference's geometric back-off (main:111-144) | "bisection"
     ess_bisect_tol: float = 1e-9      # bisection: bracket width in gamma at which the search stops
     early_reject: bool = True         # stop a solve once its proposal is certainly rejected (exact; HipEngine.set_early_reject)
+    stiff_first: bool = True          # hand the predictably long solves out first (same results; HipEngine.set_stiff_first)
     priors: dict = field(default_factory=lambda: {
         "Vmax": {"dist": "uniform", "low": 0, "high": 10},
         "Km": {"dist": "uniform", "low": 0, "high": 10},
@@ -297,6 +298,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     engine.set_resampling(s.resampling)
     if hasattr(engine, "set_early_reject"):
         engine.set_early_reject(s.early_reject)
+    if hasattr(engine, "set_stiff_first"):
+        engine.set_stiff_first(s.stiff_first)
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "particle_mutation_steps": 0}

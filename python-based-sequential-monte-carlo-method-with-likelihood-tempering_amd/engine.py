@@ -177,6 +177,12 @@ class HipEngine:
         """Stop a Michaelis-Menten solve once its proposal is certainly rejected (include/smc_hip.h: smc_set_early_reject)."""
         self._ck(self.L.smc_set_early_reject(self.ctx, int(bool(enable))), "smc_set_early_reject")
 
+    def set_stiff_first(self, enable=True):
+        """Hand the predictably long Michaelis-Menten solves out first (include/smc_hip.h: smc_set_stiff_first)."""
+        if "smc_set_stiff_first" in B.MISSING:     # A/B build of a revision before the stiff list (SMC_HIP_LIB)
+            return
+        self._ck(self.L.smc_set_stiff_first(self.ctx, int(bool(enable))), "smc_set_stiff_first")
+
     def set_resampling(self, scheme):
         """"residual_systematic" (default, Micmem_SMC_main.py:147-184) or "systematic"."""
         k = B.RESAMPLING[scheme] if isinstance(scheme, str) else int(scheme)

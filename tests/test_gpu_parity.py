@@ -813,6 +813,43 @@ def test_fused_mh_iterations_carry_their_moments(pkg, data):
         assert np.abs(out["cov_m"] - ref).max() <= 1e-11 * np.abs(ref).max()
 
 
+def test_fused_iterations_survive_interleaved_small_result_calls(pkg, data):
+    """the moments an accept kernel leaves for the NEXT fused iteration used to sit in d_small[0..12),
+    the region every small-result entry point writes (smc_max_lk_*, smc_ess_partials*, smc_moment_sums/centered_local, the
+    generic all-reduce helpers); a caller that called one of them between two fused iterations got a proposal covariance
+    built from garbage and no error.  They now live in the iteration's own buffer: with such calls interleaved, cov_m of
+    every iteration still equals np.cov of the population it starts from, and the whole sequence is bit-identical to the
+    undisturbed one."""
+    n = 30000
+    s = pkg.SMCSettings(n_particle=n)
+    w_cov = s.w_cov()
+    rs = np.random.RandomState(22)
+    th = np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((n, 3)) * np.array([0.025, 0.0295, 0.00094])
+    finals = {}
+    for disturb in (False, True):
+        with make_engine(pkg, data, n) as eng:
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            eng.loglik(pkg.SMC_SET_PRED)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+            cur = th
+            for j in range(4):
+                out = eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 5, (3 << 16) | j, 0)
+                ref = np.cov(cur.T, bias=True) * w_cov
+                assert np.abs(out["cov_m"] - ref).max() <= 1e-11 * np.abs(ref).max(), (disturb, j)
+                cur = eng.download_particles(pkg.SMC_SET_FILT)
+                if disturb:                                            # each of these writes d_small[0..]
+                    m = eng.max_lk_local()
+                    eng.ess_partials(m, np.array([0.1, 0.2, 0.3]))
+                    mean = eng.moment_sums_local() / n
+                    eng.moment_centered_local(mean)
+                    eng.max_lk_global()
+                    eng.ess_partials_global(m, np.array([0.5]))
+                    eng.comm_allreduce_sum_f64(np.arange(12.0) * 1e9)
+            finals[disturb] = (cur, eng.download_lk(pkg.SMC_SET_FILT))
+    assert np.array_equal(finals[True][0], finals[False][0]) and np.array_equal(finals[True][1], finals[False][1])
+
+
 @pytest.mark.parametrize("d", [2, 5, 8])
 def test_device_mvn_factor_any_dimension(pkg, d):
     """smc_proposal_factor_device for d != 3 (the methanation model has d = 5; SMC_MAX_DIM = 8) on a badly scaled, correlated
@@ -1084,3 +1121,57 @@ def test_early_rejection_at_one_million_particles_is_bit_identical(pkg, data):
     assert [r_["n_accept"] for r_ in a["records"]] == [r_["n_accept"] for r_ in b["records"]]
     assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
     assert a["stats"]["rk_attempts_mh"] < b["stats"]["rk_attempts_mh"]      # 2.6 % fewer attempts, a third of the time
+
+
+# ---------------------------------------------------------------------------------------------------
+# stiff-first hand-out (smc_set_stiff_first): the order in which independent solves run changes nothing
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,stiff_share", [(1, 1.0), (63, 0.5), (65, 0.0), (200, 1.0), (4099, 0.02), (50000, 0.3)])
+def test_stiff_first_handout_is_bit_identical_to_index_order(pkg, O, data, n, stiff_share):
+    """Likelihood sweep (with predictions: the WRITE_PRED instantiation, and without) and one host-RNG Metropolis
+    iteration with a third of the proposals outside the prior box, with the stiff list on and off: logL, predictions,
+    device-counted RK45 attempts, selected particles and accept flags must be bit-identical, for list sizes from empty to
+    every particle (n_stiff = n: the index-ordered pass then skips everything), particle counts around the 64-lane group
+    size, and against the oracle."""
+    rs = np.random.RandomState(n)
+    th = rs.uniform(0.05, 10, (n, 3))
+    k = int(round(n * stiff_share))
+    th[:k, 1] = th[:k, 0] / 10.0 ** rs.uniform(2.5, 3.2, k)             # Vmax / Km = 300 ... 1600: on the list
+    th[k:, 1] = np.maximum(th[k:, 1], th[k:, 0] / 200.0)               # below the threshold of 250
+    rs.shuffle(th)
+    lk_ref, _, info_ref = O.mm_loglik_batch(th, data)
+    noise = rs.standard_normal((n, 3)) * np.array([0.3, 0.001, 0.3])
+    noise[::3, 2] = 1e3                                                 # sigma far outside [0, 10]: masked proposals
+    rr = rs.uniform(0, 1, n)
+    res = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            eng.set_stiff_first(on)
+            eng.set_early_reject(False)                                 # so that the attempt counts are deterministic too
+            lk_h, pred_h, info_h = eng.loglik_host(th, want_pred=True)
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            info = eng.loglik(pkg.SMC_SET_PRED)
+            lk = eng.download_lk(pkg.SMC_SET_PRED)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, lk)
+            out = eng.mh_step_host_rng(0.01, 1.0, noise, rr)
+            res[on] = (lk_h, pred_h, info_h["rk_attempts"], lk, info["rk_attempts"], out["rk_attempts"], out["accepted_now"],
+                       eng.download_particles(pkg.SMC_SET_FILT), eng.download_lk(pkg.SMC_SET_FILT), eng.download_accept_flags())
+    a, b = res[True], res[False]
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    assert a[2] == a[4] and abs(a[2] - info_ref["n_attempts"]) <= 1e-4 * info_ref["n_attempts"]
+    assert np.max(relerr(a[3], lk_ref)) < 1e-6 and np.array_equal(a[0], a[3])    # stiff band: DESIGN.md "Parity in the stiff band"
+
+
+def test_stiff_first_full_run_is_bit_identical(pkg, data):
+    """A complete device-RNG run (early rejection on, as in the benchmark) with and without the stiff list."""
+    n = 200_000
+    runs = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            runs[on] = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n, stiff_first=on), rng="device", verbose=False, seed_device=23)
+    a, b = runs[True], runs[False]
+    assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
+    assert [r_["n_accept"] for r_ in a["records"]] == [r_["n_accept"] for r_ in b["records"]]
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]

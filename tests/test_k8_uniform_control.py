@@ -79,6 +79,68 @@ def test_k8_loop_control_is_wave_uniform(src, kernel, tmp_path):
     shutil.rmtree(tmp_path, ignore_errors=True)
 
 
+def _load_tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) and os.path.exists(OPT)), reason="needs hipcc and LLVM opt from ROCm")
+def test_mm_solve_kernel_has_no_cross_lane_operation_in_a_loop_that_lanes_leave_one_by_one(tmp_path):
+    """VERDICT r2 item 4(a).  mm_solve_kernel is the most intricate scheduler of the library (item pool, ballots, the
+    uniform tail with its v_readlane broadcast).  Its lanes DO diverge by design - every lane runs its own solve - so the
+    K8 criterion (no divergent branch at all) does not apply.  What must hold is narrower and is what the two hangs of
+    this code base violated: no cycle that the compiler's uniformity analysis reports as having a DIVERGENT EXIT (lanes
+    leave it one by one) may contain a cross-lane operation (ballot, readlane, readfirstlane, mbcnt, ds_bpermute, DPP,
+    a wave barrier) or an atomic that the atomic optimiser turns into a wave reduction.  The legitimate divergent
+    cycles are the per-lane dense-output loops, the strided LDS table fill and the `blk -= n_blk` chain; the hand-out
+    loop, the pool, the tail loop and the attempt loops must not appear.  Round 2's kernel failed this: the join of its
+    `if (lane == src)` publish was the tail loop's exit block, so the analysis (conservatively) called the whole tail loop
+    divergent and compiled the 'uniform' attempt loop with exec-mask control flow (tools/uniformity_report.py)."""
+    U = _load_tool("uniformity_report")
+    ll, uni = U.compile_ir(os.path.join(CSRC, "mm_kernels.hip"), str(tmp_path))
+    for inst in ("mm_solve_kernelILb0", "mm_solve_kernelILb1"):
+        name, cycles, n_div = U.kernel_cycles(ll, uni, inst)
+        assert n_div > 0                                   # the per-lane branches are there: the parser saw the kernel
+        bad = [(c["depth"], len(c["blocks"]), c["cross_lane"][:3]) for c in cycles if c["cross_lane"]]
+        assert not bad, f"{name}: cross-lane operations inside a cycle with a divergent exit: {bad}"
+        assert all(len(c["blocks"]) <= 8 for c in cycles), f"{name}: a large cycle has a divergent exit: " \
+            f"{[(c['depth'], len(c['blocks'])) for c in cycles]}"
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_mm_chunk_dequeue_in_the_isa(tmp_path):
+    """VERDICT r2 item 4(b) / ADVICE r2: the chunk dequeue of mm_solve_kernel.  Source form: the first lane adds kChunk,
+    the others add 0 (correct with or without LLVM's atomic optimiser).  In the ISA of both instantiations there must be
+    exactly ONE memory atomic on the queue - a 64-bit add that returns its old value - and the uniform tail's attempt
+    loop must branch on scalar conditions only (s_cbranch_vcc*, no s_*_saveexec): that is what 'wave-uniform operands'
+    buys, and what the early-rejection check silently took away in round 2."""
+    asm = str(tmp_path / "mm.s")
+    subprocess.run([HIPCC, *FLAGS, "-DSMC_ISA_MARKS", "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, "mm_kernels.hip")],
+                   check=True, stderr=subprocess.DEVNULL, timeout=600)
+    lines = open(asm).read().split("\n")
+    for inst in ("mm_solve_kernelILb0", "mm_solve_kernelILb1"):
+        start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3smc15" + inst + r"\w*:", l))
+        end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        body = [l.strip() for l in lines[start:end]]
+        atomics = [l for l in body if re.match(r"(global|flat|buffer)_atomic", l)]
+        assert len(atomics) == 1, (inst, atomics)
+        assert re.match(r"global_atomic_add_x2 v\[\d+:\d+\], ", atomics[0]) and ("sc0" in atomics[0] or "glc" in atomics[0]), atomics[0]
+        # the uniform tail's attempt loop: from the block that carries the mark to the last branch back to it
+        mk = next(i for i, l in enumerate(body) if "MARK uniform_tail_attempt" in l)
+        lab = next(i for i in range(mk, -1, -1) if re.match(r"^\.LBB\d+_\d+:", body[i]))
+        label = body[lab].split(":")[0]
+        back = [i for i in range(mk, len(body)) if re.search(r"s_c?branch\w*\s+" + re.escape(label) + r"\b", body[i])]
+        assert back, "no back edge to the uniform attempt loop found"
+        loop = [l for l in body[lab:back[-1] + 1] if l and not l.startswith(";")]
+        assert not [l for l in loop if re.match(r"s_\w+_saveexec", l)], f"{inst}: exec-mask control flow in the uniform attempt loop"
+        assert sum(1 for l in loop if l.startswith("s_cbranch_vcc")) >= 4
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
 def test_no_dequeue_behind_a_lane_id_branch():
     """The two hangs of this code base (profiles/r02_k8_dequeue_hang_isa.md) had one source shape: a value produced under
     `if (lane == 0)` (an atomicAdd on a work queue) and then read by every lane through v_readfirstlane / __shfl.  The
