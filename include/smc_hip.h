@@ -180,6 +180,13 @@ int smc_ess_partials(smc_ctx *ctx, double max_lk, const double *gm, int n_cand, 
  * device->host->device->host round trip per collective.  With one rank (no communicator) they equal the calls above. */
 int smc_max_lk_global(smc_ctx *ctx, double *max_lk);
 int smc_ess_partials_global(smc_ctx *ctx, double max_lk, const double *gm, int n_cand, double *sum_w, double *sum_w2);
+/* One call, ONE synchronisation for a batch of the back-off search (Micmem_SMC_main.py:116-134): max(lk) over all ranks
+ * (with_max != 0; it stays on the device), then the sums of up to 32 candidate increments in two back-to-back 16-candidate
+ * passes that read the maximum from device memory, one all-reduce, one read-back.  sum_w / sum_w2: n_cand values, the same
+ * numbers smc_max_lk_global + smc_ess_partials_global return (same kernels, same order of additions).  with_max == 0 reuses
+ * the maximum of the previous call (the search going on beyond its first 32 candidates). */
+int smc_ess_search_global(smc_ctx *ctx, const double *gm, int n_cand, int with_max, double *max_lk, double *sum_w,
+                          double *sum_w2);
 
 /* ---- A5: residual-systematic resampling (Micmem_SMC_main.py:147-184) ------------------------ */
 /* Phase 1: with w_i = exp((lk_i-max_lk)*gm)/sum_weight_global, p_is_i = trunc(w_i*N_global) and the

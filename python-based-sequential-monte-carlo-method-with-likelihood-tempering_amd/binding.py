@@ -70,6 +70,7 @@ SIGNATURES = {
     "smc_ess_partials": (cint, [c_ctx, f64, c_dp, cint, c_dp, c_dp]),
     "smc_max_lk_global": (cint, [c_ctx, c_dp]),
     "smc_ess_partials_global": (cint, [c_ctx, f64, c_dp, cint, c_dp, c_dp]),
+    "smc_ess_search_global": (cint, [c_ctx, c_dp, cint, cint, c_dp, c_dp, c_dp]),
     "smc_resample_global": (cint, [c_ctx, f64, f64, f64, f64, cint, c_i64p, c_i64p]),
     "smc_mh_iteration_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, i64, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "smc_mh_iteration_last_transform": (cint, [c_ctx, c_dp]),

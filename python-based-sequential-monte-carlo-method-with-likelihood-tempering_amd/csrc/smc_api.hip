@@ -676,6 +676,46 @@ int smc_ess_partials_global(smc_ctx *c, double max_lk, const double *gm, int n_c
     return 0;
 }
 
+// Micmem_SMC_main.py:116-134 for a whole batch of back-off candidates with ONE read-back: max(lk) -> [all-reduce MAX] stays
+// on the device, up to two 16-candidate ESS passes read it from there back to back -> [ONE all-reduce SUM] -> one copy of
+// (max_lk, sums) to the host.  Round 2 needed one round trip for the maximum and one per 16 candidates (318 launches and as
+// many synchronisations for the 3 044 search iterations of the benchmark's 20 runs; the first step alone needs 17-18
+// candidates).  with_max == 0: max(lk) is still in place from the previous call of the same search (candidates 33 ...).
+int smc_ess_search_global(smc_ctx *c, const double *gm, int n_cand, int with_max, double *max_lk, double *sum_w, double *sum_w2) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (n_cand < 1 || n_cand > 2 * SMC_MAX_ESS_CAND) return fail(c, "smc_ess_search_global: n_cand must be 1 .. 32");
+    HIPC(c, hipSetDevice(c->device));
+    constexpr int kMaxAt = 200, kSumsAt = 208;       // d_small layout of this call: [kMaxAt] max(lk), [kSumsAt ..) 2 x 32 sums
+    double *S = c->d_small;
+    if (with_max) {
+        {
+            ScopedTimer tm(c, SMC_T_MAX);
+            launch_max(c, c->set[SMC_SET_PRED].lk, c->n_local, S + kMaxAt);
+        }
+        if (dev_allreduce(c, S + kMaxAt, 1, ncclDouble, ncclMax)) return 1;
+    }
+    const int n_a = n_cand < SMC_MAX_ESS_CAND ? n_cand : SMC_MAX_ESS_CAND, n_b = n_cand - n_a;
+    const int pad_a = ess_padded_k(n_a), pad_b = n_b > 0 ? ess_padded_k(n_b) : 0;
+    {
+        ScopedTimer tm(c, SMC_T_ESS);
+        launch_ess(c, c->set[SMC_SET_PRED].lk, c->n_local, 0.0, gm, n_a, S + kSumsAt, S + kMaxAt);
+        if (n_b > 0) launch_ess(c, c->set[SMC_SET_PRED].lk, c->n_local, 0.0, gm + n_a, n_b, S + kSumsAt + 2 * pad_a, S + kMaxAt);
+    }
+    HIPC(c, hipGetLastError());
+    const int nv = 2 * (pad_a + pad_b);
+    if (dev_allreduce(c, S + kSumsAt, (size_t)nv, ncclDouble, ncclSum)) return 1;
+    HIPC(c, hipMemcpyAsync(c->h_small + kMaxAt, S + kMaxAt, (size_t)(kSumsAt - kMaxAt + nv) * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (max_lk) *max_lk = c->h_small[kMaxAt];
+    for (int k = 0; k < n_cand; ++k) {
+        const int at = kSumsAt + (k < n_a ? 2 * k : 2 * pad_a + 2 * (k - n_a));
+        sum_w[k] = c->h_small[at];
+        sum_w2[k] = c->h_small[at + 1];
+    }
+    return 0;
+}
+
 int smc_resample_global(smc_ctx *c, double max_lk, double gm, double sum_weight_global, double wrand, int first_step,
                         int64_t *n_offspring, int64_t *count_sum) {
     if (!c) return fail(nullptr, "NULL context");

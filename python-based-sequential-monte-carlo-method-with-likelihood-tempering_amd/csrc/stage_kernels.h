@@ -7,7 +7,9 @@ void launch_aos_to_soa(smc_ctx *c, const double *aos, double *soa, int64_t n, in
 void launch_soa_to_aos(smc_ctx *c, const double *soa, double *aos, int64_t n, int d, int64_t stride);
 void launch_sample_prior(smc_ctx *c, uint64_t seed, int64_t goff);
 void launch_max(smc_ctx *c, const double *lk, int64_t n, double *d_out);
-void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const double *gm, int k, double *d_out);
+// max_lk_dev != nullptr: max(lk) is read from device memory (left there by launch_max / an all-reduce earlier on the stream)
+void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const double *gm, int k, double *d_out,
+                const double *max_lk_dev = nullptr);
 int ess_padded_k(int k);
 void launch_moment_sums(smc_ctx *c, double *d_out);
 void launch_moment_centered(smc_ctx *c, const double *mean, double *d_out);

@@ -189,8 +189,12 @@ __device__ __forceinline__ void wave_sum_transposed(double (&v)[NV], int lane) {
 }
 
 template <int K>
-__global__ void __launch_bounds__(kScanBlock) ess_partial_kernel(const double *__restrict__ lk, int64_t n, double max_lk,
-                                                                 EssCand cand, double *__restrict__ partials) {
+__global__ void __launch_bounds__(kScanBlock) ess_partial_kernel(const double *__restrict__ lk, int64_t n, double max_lk_val,
+                                                                 const double *__restrict__ max_lk_dev, EssCand cand,
+                                                                 double *__restrict__ partials) {
+    // max(lk) either by value (the caller has read it back) or from device memory (fused search: the max kernels and the
+    // all-reduce that precede this pass on the stream left it there - no host round trip in between)
+    const double max_lk = max_lk_dev ? *max_lk_dev : max_lk_val;
     constexpr int NV = 2 * K;                          // value 2k = sum of weights, 2k + 1 = sum of squared weights
     constexpr int kShift = NV == 2 ? 5 : NV == 8 ? 3 : NV == 16 ? 2 : 1;   // 6 - log2(NV)
     static_assert(NV == 2 || NV == 8 || NV == 16 || NV == 32, "K must be 1, 4, 8 or 16");
@@ -691,7 +695,8 @@ void launch_max(smc_ctx *c, const double *lk, int64_t n, double *d_out) {
     hipLaunchKernelGGL(max_partial_kernel, dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, c->d_partials);
     hipLaunchKernelGGL(max_final_kernel, dim3(1), dim3(kScanBlock), 0, c->stream, c->d_partials, g, d_out);
 }
-void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const double *gm, int k, double *d_out) {
+void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const double *gm, int k, double *d_out,
+                const double *max_lk_dev) {
     EssCand cand{};
     cand.k = k;
     for (int i = 0; i < SMC_MAX_ESS_CAND; ++i) cand.gm[i] = (i < k) ? gm[i] : 0.0;
@@ -699,19 +704,19 @@ void launch_ess(smc_ctx *c, const double *lk, int64_t n, double max_lk, const do
     int K;
     if (k <= 1) {
         K = 1;
-        hipLaunchKernelGGL((ess_partial_kernel<1>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+        hipLaunchKernelGGL((ess_partial_kernel<1>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, max_lk_dev, cand,
                            c->d_partials);
     } else if (k <= 4) {
         K = 4;
-        hipLaunchKernelGGL((ess_partial_kernel<4>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+        hipLaunchKernelGGL((ess_partial_kernel<4>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, max_lk_dev, cand,
                            c->d_partials);
     } else if (k <= 8) {
         K = 8;
-        hipLaunchKernelGGL((ess_partial_kernel<8>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+        hipLaunchKernelGGL((ess_partial_kernel<8>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, max_lk_dev, cand,
                            c->d_partials);
     } else {
         K = 16;
-        hipLaunchKernelGGL((ess_partial_kernel<16>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, cand,
+        hipLaunchKernelGGL((ess_partial_kernel<16>), dim3(g), dim3(kScanBlock), 0, c->stream, lk, n, max_lk, max_lk_dev, cand,
                            c->d_partials);
     }
     // a second launch for the 2K sums over the blocks' rows: letting the last block to finish do it (ticket + __threadfence)

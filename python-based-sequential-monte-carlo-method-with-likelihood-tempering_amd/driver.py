@@ -130,31 +130,52 @@ def _ess_sums(engine, comm, max_lk, gms):
 
 
 def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_MAX_ESS_CAND):
-    """main:111-144.  Candidates are evaluated `chunk` at a time by one fused pass over lk each."""
+    """main:111-144.  Candidates are evaluated `chunk` at a time by one fused pass over lk each.  With the reductions in
+    the engine (one rank / RCCL) the maximum and the first 32 candidates of the grid cost ONE synchronisation
+    (smc_ess_search_global): the back-off grid gamma_old + (1 - gamma_old) * 0.7^k is known in advance, the decision which
+    candidate is the first to pass is the reference's own expression on the returned sums."""
     n = s.n_particle
-    max_lk = _max_lk(engine, comm)                                            # :116
-    if s.ess_search == "bisection":
-        return ess_bisection(engine, comm, gamma_old, s, max_lk, chunk)
+    fused = _on_device(comm) and s.ess_search != "bisection" and hasattr(engine, "ess_search_global")
     gms, gammas, gamma_after_all = ess_candidates(gamma_old, s)
+    if fused:
+        # the first tempering step needs 17-18 candidates (gamma_1 ~ 2e-3 = 0.7^17), later ones fewer than 16
+        first = 2 * chunk if gamma_old == 0.0 else chunk
+        max_lk, sw0, sw20 = engine.ess_search_global(gms[:first], with_max=True)
+    else:
+        max_lk = _max_lk(engine, comm)                                        # :116
+        if s.ess_search == "bisection":
+            return ess_bisection(engine, comm, gamma_old, s, max_lk, chunk)
     iters = 0
     launches = 0
+    syncs = 0 if fused else 1                                                 # the maximum's own round trip
     ess = sum_w = None
     k0 = 0
     while k0 < len(gms):
-        part = gms[k0:k0 + chunk]
-        sw, sw2 = _ess_sums(engine, comm, max_lk, part)
-        launches += 1
+        if fused:
+            width = (2 * chunk if gamma_old == 0.0 else chunk) if k0 == 0 else 2 * chunk
+            part = gms[k0:k0 + width]
+            if k0 == 0:
+                sw, sw2 = sw0, sw20
+            else:
+                _, sw, sw2 = engine.ess_search_global(part, with_max=False)
+            launches += (len(part) + chunk - 1) // chunk
+        else:
+            width = chunk
+            part = gms[k0:k0 + chunk]
+            sw, sw2 = _ess_sums(engine, comm, max_lk, part)
+            launches += 1
+        syncs += 1
         for i in range(len(part)):
             sum_w = float(sw[i])
             ess = 1.0 / (float(sw2[i]) / (sum_w * sum_w)) / n                 # :130-134
             iters += 1
             if ess > s.ess_limit:                                             # :136
                 return {"gamma_new": gammas[k0 + i], "gm": part[i], "ess": ess, "sum_weight": sum_w, "max_lk": max_lk,
-                        "iters": iters, "launches": launches, "warning": False}
-        k0 += chunk
+                        "iters": iters, "launches": launches, "syncs": syncs, "warning": False}
+        k0 += width
     # no candidate passed: the weights of the last trial are kept, gamma has been shrunk once more (:141-144)
     return {"gamma_new": gamma_after_all, "gm": gms[-1], "ess": ess, "sum_weight": sum_w, "max_lk": max_lk,
-            "iters": iters, "launches": launches, "warning": True}
+            "iters": iters, "launches": launches, "syncs": syncs, "warning": True}
 
 
 def ess_bisection(engine, comm, gamma_old: float, s: SMCSettings, max_lk: float, chunk: int = SMC_MAX_ESS_CAND):
@@ -176,7 +197,8 @@ def ess_bisection(engine, comm, gamma_old: float, s: SMCSettings, max_lk: float,
     sw, ess = evaluate([hi_gm])
     if ess[0] > s.ess_limit:                       # the whole remaining increment passes
         return {"gamma_new": g_hi, "gm": hi_gm, "ess": float(ess[0]), "sum_weight": float(sw[0]),   # g_hi: exactly 1.0 at the end
-                "max_lk": max_lk, "iters": state["iters"], "launches": state["launches"], "warning": False}
+                "max_lk": max_lk, "iters": state["iters"], "launches": state["launches"], "syncs": 1 + state["launches"],
+                "warning": False}
     lo_gm, best = 0.0, None
     while hi_gm - lo_gm > s.ess_bisect_tol:
         gms = lo_gm + (hi_gm - lo_gm) * np.arange(1, chunk + 1) / (chunk + 1)
@@ -194,7 +216,7 @@ def ess_bisection(engine, comm, gamma_old: float, s: SMCSettings, max_lk: float,
         best = (hi_gm, float(ess[0]), float(sw[0]))
     gm, e, w = best
     return {"gamma_new": gamma_old + gm, "gm": gm, "ess": e, "sum_weight": w, "max_lk": max_lk,
-            "iters": state["iters"], "launches": state["launches"], "warning": e <= s.ess_limit}
+            "iters": state["iters"], "launches": state["launches"], "syncs": 1 + state["launches"], "warning": e <= s.ess_limit}
 
 
 def resample(engine, comm, es: dict, wrand_u: float, s: SMCSettings, first_step: bool):
@@ -302,7 +324,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         engine.set_stiff_first(s.stiff_first)
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
-             "ess_launches": 0, "particle_mutation_steps": 0}
+             "ess_launches": 0, "ess_syncs": 0, "ess_search_s": 0.0, "particle_mutation_steps": 0}
 
     meth = getattr(engine, "model", ("",))[0] == "methanation"
 
@@ -360,10 +382,13 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     records = []
     step = 0
     for step in range(first_step_no, s.itr_max):                                          # :109
+        t_search = time.perf_counter()
         es = ess_search(engine, comm, gamma_old, s)                           # :111-144
+        stats["ess_search_s"] += time.perf_counter() - t_search              # wall time of the search: max + passes + read-backs
         gamma_new, ess, max_lk = es["gamma_new"], es["ess"], es["max_lk"]
         stats["ess_iters"] += es["iters"]
         stats["ess_launches"] += es["launches"]
+        stats["ess_syncs"] += es.get("syncs", es["launches"] + 1)
         if verbose and rank == 0:
             if es["warning"]:
                 log("ess reduction warning: ess = ", ess)

@@ -266,6 +266,17 @@ class HipEngine:
                  "smc_ess_partials_global")
         return sw, sw2
 
+    def ess_search_global(self, gms, with_max=True):
+        """max(lk) and the weight sums of up to 32 candidate increments, all ranks, one synchronisation
+        (include/smc_hip.h: smc_ess_search_global) -> (max_lk, sum_w, sum_w2)."""
+        gms = _f64(gms)
+        k = gms.shape[0]
+        sw, sw2 = np.empty(k), np.empty(k)
+        m = ctypes.c_double(0)
+        self._ck(self.L.smc_ess_search_global(self.ctx, _dp(gms), k, int(bool(with_max)), ctypes.byref(m), _dp(sw), _dp(sw2)),
+                 "smc_ess_search_global")
+        return m.value, sw, sw2
+
     def resample_global(self, max_lk, gm, sum_w, wrand, first_step):
         o, cs = ctypes.c_int64(0), ctypes.c_int64(0)
         self._ck(self.L.smc_resample_global(self.ctx, float(max_lk), float(gm), float(sum_w), float(wrand),

@@ -168,6 +168,14 @@ class OracleEngine:
             sw, sw2 = tot[:len(gms)], tot[len(gms):]
         return sw, sw2
 
+    def ess_search_global(self, gms, with_max=True):
+        """include/smc_hip.h: smc_ess_search_global - maximum + up to 32 candidates, one synchronisation."""
+        assert 1 <= len(gms) <= 32
+        if with_max:
+            self._search_max = self.max_lk_global()
+        sw, sw2 = self.ess_partials_global(self._search_max, gms)
+        return self._search_max, sw, sw2
+
     def resample_global(self, max_lk, gm, sum_w, wrand, first_step):
         c = self._comm()
         r_loc, c_loc = self.resample_phase1(max_lk, gm, sum_w)

@@ -1175,3 +1175,24 @@ def test_stiff_first_full_run_is_bit_identical(pkg, data):
     assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
     assert [r_["n_accept"] for r_ in a["records"]] == [r_["n_accept"] for r_ in b["records"]]
     assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+
+
+@pytest.mark.parametrize("n_cand", [1, 5, 16, 17, 32])
+def test_fused_ess_search_equals_max_plus_partials(pkg, data, n_cand):
+    """smc_ess_search_global (maximum + up to 32 candidates, ONE synchronisation; the ESS passes read max(lk) from device
+    memory) returns bit for bit what smc_max_lk_global followed by smc_ess_partials_global per 16 candidates returns."""
+    n = 300_000
+    rs = np.random.RandomState(n_cand)
+    lk = -np.abs(rs.standard_normal(n)) * 300 + 250
+    gms = 0.7 ** np.arange(n_cand)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_lk(pkg.SMC_SET_PRED, lk)
+        m, sw, sw2 = eng.ess_search_global(gms)
+        m_ref = eng.max_lk_global()
+        ref = [eng.ess_partials_global(m_ref, gms[k:k + 16]) for k in range(0, n_cand, 16)]
+        _, sw_again, _ = eng.ess_search_global(gms[:3], with_max=False)       # the maximum stays in place between calls
+    assert m == m_ref == lk.max()
+    assert np.array_equal(sw, np.concatenate([r[0] for r in ref])) and np.array_equal(sw2, np.concatenate([r[1] for r in ref]))
+    assert np.array_equal(sw_again, sw[:3])
+    w = np.exp((lk - lk.max())[None, :] * gms[:, None])
+    assert np.allclose(sw, w.sum(axis=1), rtol=1e-12) and np.allclose(sw2, (w * w).sum(axis=1), rtol=1e-12)
