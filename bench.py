@@ -313,6 +313,28 @@ def bench_methanation(args):
     if args.meth_sweeps > 0:
         return bench_methanation_sweeps(args, pkg, eng, s, n)
     comm = make_comm(pkg, eng, rank, world)
+    s.early_reject = not args.no_early_reject
+    if args.progress and rank == 0:      # a config-4 run lasts many minutes: one line per sweep on stderr (and in a file the
+        t_begin = time.perf_counter()    # GPU box's watchdog can see), so that a long run does not look hung
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        prog = open(os.path.join(ROOT, "gpurun_out", "bench_methanation_progress.log"), "a")
+
+        def wrap(name):
+            f = getattr(eng, name)
+
+            def w(*a, **k):
+                out = f(*a, **k)
+                chk = eng.meth_sweep_check()
+                line = (f"[{time.perf_counter() - t_begin:8.1f} s] {name}: gamma {a[0] if name != 'loglik' else 0.0:.6g}, "
+                        f"{chk['completed_solves']} solved + {chk.get('cancelled_solves', 0)} cancelled of {chk['expected_solves']}"
+                        + (f", accepted {out.get('accepted_now')}" if isinstance(out, dict) and "accepted_now" in out else ""))
+                print(line, file=sys.stderr, flush=True)
+                prog.write(line + "\n")
+                prog.flush()
+                return out
+            setattr(eng, name, w)
+        for nm in ("loglik", "mh_iteration_device_rng"):
+            wrap(nm)
     for i in range(args.warmup):
         pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=900 + i)
     eng.timing_enable(True)
@@ -331,7 +353,8 @@ def bench_methanation(args):
         return
     pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)
     sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs) + args.steps
-    solves = sweeps * n * 30
+    solves = sum(o["stats"].get("dae_solves", 0) for o in outs)                       # device-counted: solves actually done
+    cancelled = sum(o["stats"].get("dae_solves_cancelled", 0) for o in outs)          # ... and skipped by exact early rejection
     k8 = {k: sum(o["stats"].get(k, 0) for o in outs) for k in ("bdf_steps", "newton_iters", "factorisations", "failed_solves")}
     k8_flop = k8["factorisations"] * FLOP_PER_FACTORISATION + k8["newton_iters"] * FLOP_PER_NEWTON_ITERATION
     print(json.dumps({
@@ -340,10 +363,13 @@ def bench_methanation(args):
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "methanation kinetics (30 experiments x 357-state DAE per particle), adaptive tempering, "
                                "reference defaults; one step = one full SMC run; synthetic inlet table and observations",
-                   "particles_per_gpu": n, "rng": "device Philox4x32-10", "parity": "K8 unpinned (no IDA in the image)"},
-        "dae_solves_per_s": solves / (tm["solve"]["ms"] * 1e-3), "dae_solves": solves,
+                   "particles_per_gpu": n, "rng": "device Philox4x32-10", "parity": "K8 unpinned (no IDA in the image)",
+                   "early_reject": bool(s.early_reject)},
+        "dae_solves_per_s": solves / (tm["solve"]["ms"] * 1e-3), "dae_solves": solves, "dae_solves_cancelled": cancelled,
+        "dae_solves_without_early_rejection": solves + cancelled,
         "tempering_steps_per_run": [o["step"] for o in outs], "mutation_sweeps": sweeps - args.steps,
-        "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(), "kernel_ms": tm,
+        "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(), "posterior_std": outs[-1]["p_pred"].std(axis=0).tolist(),
+        "logZ": [o["logZ"] for o in outs], "kernel_ms": tm,
         "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF)", "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
                      "achieved": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
@@ -419,6 +445,8 @@ def main():
                     help="A/B switch: complete every solve even when its proposal is already certain to be rejected (SMCSettings.early_reject)")
     ap.add_argument("--no-stiff-first", action="store_true",
                     help="A/B switch: hand the (particle, experiment) solves out in plain index order (SMCSettings.stiff_first)")
+    ap.add_argument("--progress", action="store_true",
+                    help="methanation only: one line per sweep on stderr and in gpurun_out/bench_methanation_progress.log")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # no launcher: become one (no GPU call in this process)

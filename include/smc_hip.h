@@ -101,10 +101,16 @@ int smc_user_model_check(const char *source, int n_states, int dim, char *log, i
 int smc_meth_sweep_counters(smc_ctx *ctx, int64_t out[4]);
 /* Completeness of the LAST methanation sweep: out = {DAE solves asked for (live (particle, experiment) pairs), solves
  * finished, live items whose status was still the pre-sweep poison value when the likelihood was formed, waves that were
- * incomplete at a dequeue}.  A sweep with out[1] != out[0] or out[2], out[3] != 0 makes smc_loglik / smc_mh_step_* fail
- * (the reference's counterpart is the bare except of methanation_set_likelihood.py:234-254: there a lost solve would
- * surface as an exception at ray.get). */
-int smc_meth_sweep_check(smc_ctx *ctx, int64_t out[4]);
+ * incomplete at a dequeue, solves NOT started because their proposal was already certain to be rejected}.  A sweep with
+ * out[1] + out[4] != out[0] or out[2], out[3] != 0 makes smc_loglik / smc_mh_step_* fail (the reference's counterpart is
+ * the bare except of methanation_set_likelihood.py:234-254: there a lost solve would surface as an exception at ray.get).
+ * Exact early rejection (smc_set_early_reject, default on) also covers the methanation sweeps: the accept test
+ * exp((lk2 - lk1) * gamma) >= rr (SMC_methanation_main.py:376-383) has lk1 and rr fixed beforehand and my_loglike only
+ * falls with every experiment added to it, so a proposal that fails the test on the experiments finished SO FAR is
+ * rejected exactly as the full computation would reject it and its remaining DAE solves are skipped (out[4]); the sweep
+ * runs experiment-major so that a proposal's experiments come up one after the other.  p_filt, lk1, accept flags and
+ * counts are unchanged; lk2 of such a proposal is never formed (debug capture switches the feature off). */
+int smc_meth_sweep_check(smc_ctx *ctx, int64_t out[5]);
 /* Outlet flows (n x n_data x 5, the F_k of methanation_set_likelihood.py:204-208; -10000 where the solve failed, :244-249)
  * and solver status (n x n_data: 0 solved, 1 given up, -1 not solved in this sweep = masked proposal) of the LAST sweep -
  * what my_model returns per particle before my_loglike reduces it (the reference keeps them as C_l_ for its plots). */
@@ -142,6 +148,16 @@ int smc_set_early_reject(smc_ctx *ctx, int enable);
  * one-Ray-task-per-particle fan-out (Micmem_likelihood.py:83-87) leaves it to its scheduler too; 0 restores round 2's
  * plain index order (A/B timing, tests). */
 int smc_set_stiff_first(smc_ctx *ctx, int enable);
+/* Parity mode of the Michaelis-Menten step controller (default: off).  SciPy evaluates error_norm ** -0.2 (rk.py:155,169)
+ * and x ** (1 / 5) (common.py:130) with libm's pow and the DOUBLE exponents -0.2 / 0.2 (= 1/5 + 1.1e-17).  The fast
+ * device form (hardware log2 / exp2 seed + one correction, <= 1.5 ulp about the fifth root) differs from that in the last
+ * bit of many arguments; on RK45's stability limit one such bit can flip one accept / reject decision and the solve then
+ * follows another, equally valid step sequence (logL equal to 1e-8 ... 1e-6 only).  enable != 0 finishes the fast value to
+ * the CORRECTLY ROUNDED pow(x, -0.2) / pow(x, 0.2) (double-double residual, csrc/pow_fifth_exact.h; checked against a 113-bit
+ * reference on the CPU) at ~15 more operations per attempt: what libm returns except for about 8 of 10^4 arguments where
+ * glibc's own pow is not correctly rounded.  run_smc switches it on with rng="numpy" (the reference's stream) and the
+ * drop-in sim_particle uses it; the device-RNG default keeps the fast form. */
+int smc_set_exact_pow(smc_ctx *ctx, int enable);
 int smc_set_resampling(smc_ctx *ctx, int scheme);
 
 /* ---- particle movement -------------------------------------------------------------------- */

@@ -17,15 +17,81 @@ namespace smc {
 
 using namespace meth;
 
-constexpr int kStatusUnsolved = -1;   // what launch_solves fills the status array with before a sweep
+constexpr int kStatusUnsolved = -1;    // what launch_solves fills the status array with before a sweep
+constexpr int kStatusCancelled = -2;   // not solved: the proposal was already certain to be rejected (meth_certainly_rejected)
 
-// work list of an MH sweep: the (particle, experiment) pairs of proposals inside the prior support; queue[1] counts them
-__global__ void meth_worklist_kernel(const uint8_t *__restrict__ p0mask, int64_t n, int n_data, int64_t *__restrict__ list,
+// my_loglike (methanation_set_likelihood.py:280-300) in two pieces that BOTH the likelihood kernel and the early-rejection
+// bound go through, so that the bound is an upper bound of the value the likelihood kernel forms in floating point too:
+//   acc_i  = sum over the experiments e, in order, of (flow[e][i] - obs[i][e])^2         (:289-294, one species i)
+//   logL   = sum over the species i, in order, of  -0.5/sigma^2 * acc_i - n_data*log(sigma)   (:295-298)
+// Every operation is monotone (round-to-nearest preserves order), so leaving an experiment out - a zero in place of its
+// non-negative square - can only raise the result.
+__device__ __forceinline__ double meth_acc_step(double acc, double d) { return acc + d * d; }
+__device__ __forceinline__ double meth_loglike_step(double total, double c, double acc, double l) { return total + (c * acc - l); }
+
+// the live proposals of an MH sweep, compacted (order irrelevant); queue[1] counts them
+__global__ void meth_livelist_kernel(const uint8_t *__restrict__ p0mask, int64_t n, int64_t *__restrict__ list,
                                      unsigned long long *__restrict__ queue) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n || p0mask[p] == 0) return;   // masked proposal: lk2 == lk1, nothing to solve
-    const unsigned long long base = atomicAdd(&queue[1], (unsigned long long)n_data);
-    for (int e = 0; e < n_data; ++e) list[base + e] = p * n_data + e;
+    list[atomicAdd(&queue[1], 1ULL)] = p;   // one atomic per live lane: no cross-lane read follows, correct with or without the atomic optimiser
+}
+
+// EXACT early rejection for the methanation sweeps (the Michaelis-Menten counterpart is
+// mm_certainly_rejected in mm_kernels.hip).  The accept test of the sweep, exp((lk2 - lk1) * gamma) [* p0_2/p0_1] >= rr
+// (SMC_methanation_main.py:376-383), has lk1 and rr fixed before the proposal is solved, and lk2 = my_loglike only falls
+// with every experiment that is added to it: each contributes five non-negative squares times -0.5/sigma^2 (a failed
+// solve's -10000 flows - :244-249 - are just very large squares).  So the likelihood formed from the experiments of the
+// particle that HAVE finished is an upper bound of lk2, and if even that bound fails the test the proposal is rejected
+// whatever its remaining 357-state DAE solves would give: they are not started.  Unlike the Michaelis-Menten path a solve
+// contributes nothing before it ends (the flows are read off the final state), so the saving comes from the ORDER of the
+// work: the sweep runs experiment-major - experiment 0 of every live proposal, then experiment 1, ... - and by the time
+// the later experiments of a proposal come up its earlier ones have long finished.  Nothing observable changes (p_filt,
+// lk1, accept flags and counts are those of the full computation); the solve counters are smaller.
+// Called by the whole wave before a solve: lane e looks at experiment e of the particle; the sums run in the likelihood
+// kernel's order on every lane (v_readlane broadcast), so the result is wave-uniform.  n_data <= 64.
+// Not inlined on purpose: the caller is the 512-VGPR integrator kernel, and folding this code into it made its register
+// allocation spill twice as much into scratch; as a function with scalar arguments it gets its own allocation and costs
+// one call per solve.
+__device__ __attribute__((noinline)) bool meth_certainly_rejected(const RejectArgs *rp, const double *obs, int n_data,
+                                                                  double sigma, int64_t p, const double *flows,
+                                                                  const int *status, int lane) {
+    const RejectArgs &r = *rp;
+    double dv[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    bool cancelled = false;
+    if (lane < n_data) {
+        const int64_t w = p * n_data + lane;
+        // the solving wave publishes flows, then status with release semantics at agent scope (L2 is per XCD)
+        const int st = __hip_atomic_load(status + w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        cancelled = (st == kStatusCancelled);
+        if (st >= 0) {
+#pragma unroll
+            for (int f = 0; f < 5; ++f) {
+                const double fl = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(flows) + (w * 5 + f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                dv[f] = fl - obs[f * n_data + lane];
+            }
+        }
+    }
+    if (__ballot(cancelled) != 0ull) return true;     // a sibling has already established the rejection
+    const double c = -(0.5 / (sigma * sigma)), l = n_data * log(sigma);
+    double total = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        double acc = 0.0;
+        for (int e = 0; e < n_data; ++e) acc = meth_acc_step(acc, lane_bcast(dv[i], e));   // 0 for an unfinished experiment
+        total = meth_loglike_step(total, c, acc, l);
+    }
+    double rr;
+    if (r.device_rng) {
+        const u32x4 ru = philox_block(r.seed, (uint64_t)(r.global_offset + p), r.stream, SMC_PHILOX_BLOCK_UNIFORM);
+        rr = u01_from(ru.x, ru.y);
+    } else {
+        rr = r.rr[p];
+    }
+    double pp = exp((total - r.lk1[p]) * r.gamma);
+    if (r.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * r.pratio[p];
+    return pp < rr * (1.0 - 1e-12);   // the margin covers a last-bit non-monotonicity of exp; any NaN: false
 }
 
 // K8 over (particle, experiment) pairs of the resident set; one wave per solve (meth_dae_elem.h), persistent waves
@@ -36,27 +102,50 @@ __global__ void meth_worklist_kernel(const uint8_t *__restrict__ p0mask, int64_t
 // Bookkeeping for the host (smc_meth_sweep_check): expected = count, completed += 1 per finished solve, wave_split.
 __global__ void __launch_bounds__(64)
 meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
-                          const int64_t *__restrict__ list, double *__restrict__ flows, int *__restrict__ status,
+                          const int64_t *__restrict__ live, double *flows, int *status, const RejectArgs *__restrict__ rej,
                           SweepCounters *__restrict__ counters, unsigned long long *__restrict__ queue) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const DViewE D{lds + kLdsD, lane};
-    const int64_t count = list ? (int64_t)queue[1] : n * m.n_data;
+    // EXPERIMENT-MAJOR order: position q = e * n_live + j is experiment e of the j-th live particle, so that the experiments
+    // of one proposal come up one after the other, n_live positions apart, and the later ones can be cancelled on the
+    // strength of the earlier ones (meth_certainly_rejected).  Which experiment is solved first cannot change a result.
+    const int64_t n_live = live ? (int64_t)queue[1] : n;
+    const int64_t count = n_live * m.n_data;
     if (blockIdx.x == 0 && lane == 0) counters->expected_solves = (unsigned long long)count;
     unsigned split = 0;
     for (int64_t it = 0; it <= count; ++it) {
         const int64_t pos = wave_dequeue(&queue[0], lane, split);
         if (pos >= count) break;
-        const int64_t w = list ? list[pos] : pos;
-        const int64_t particle = w / m.n_data;
-        const int e = (int)(w - particle * m.n_data);
+        const int e = (int)(pos / n_live);
+        const int64_t j = pos - (int64_t)e * n_live;
+        const int64_t particle = live ? live[j] : j;
+        const int64_t w = particle * m.n_data + e;
+        if (rej) {
+            // wave-uniform by construction (every lane runs the same sums on broadcast operands); the v_readfirstlane tells
+            // the compiler so - the atomic loads inside are a divergence source for its analysis
+            double sigma = m.sigma_fixed;
+            if (m.est_sigma) {
+                sigma = m.base[8];
+                for (int kq = 0; kq < m.dim; ++kq)
+                    if (m.est_pos[kq] == 8) sigma = theta[kq * stride + particle];
+            }
+            if (__builtin_amdgcn_readfirstlane((int)meth_certainly_rejected(rej, m.obs, m.n_data, sigma, particle, flows, status, lane))) {
+                // no `if (lane == 0)` in front of the `continue`: the join of such a branch would be the loop's latch, and the
+                // compiler's uniformity analysis then calls the whole dequeue loop - DPP, permlane and all - a cycle with a
+                // divergent exit (tests/test_k8_uniform_control.py).  Every lane stores the same word; lane 0 counts.
+                __hip_atomic_store(status + w, kStatusCancelled, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&counters->cancelled_solves, lane == 0 ? 1ULL : 0ULL);
+                continue;
+            }
+        }
         double p[18];
         for (int q = 0; q < 10; ++q) p[q] = m.cond[e * 10 + q];
-        for (int j = 0; j < 8; ++j) {  // p_pred_bases[:, est_position] = particle (methanation_functions.py:80)
-            double v = m.base[j];
+        for (int jj = 0; jj < 8; ++jj) {  // p_pred_bases[:, est_position] = particle (methanation_functions.py:80)
+            double v = m.base[jj];
             for (int kq = 0; kq < m.dim; ++kq)
-                if (m.est_pos[kq] == j) v = theta[kq * stride + particle];
-            p[10 + j] = v;
+                if (m.est_pos[kq] == jj) v = theta[kq * stride + particle];
+            p[10 + jj] = v;
         }
         if (lane < kNX)
             for (int f = 0; f < 7; ++f) {
@@ -70,17 +159,23 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
             const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
             for (int f = 0; f < 5; ++f) {
                 const double cc = D(0, f);
-                flows[w * 5 + f] = (st.status == 0)
-                                       ? cc * m.S * u * 60 * k::R * T / (P_total) * 1e6 * (P_total) / m.P_stp * 298 / T
-                                       : -10000.0;   // methanation_set_likelihood.py:244-249
+                const double fl = (st.status == 0)
+                                      ? cc * m.S * u * 60 * k::R * T / (P_total) * 1e6 * (P_total) / m.P_stp * 298 / T
+                                      : -10000.0;   // methanation_set_likelihood.py:244-249
+                // visible to the waves of other XCDs while the kernel runs: agent-scope stores, the status last (release)
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(flows) + (w * 5 + f),
+                                   (unsigned long long)__double_as_longlong(fl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            status[w] = st.status;
+            __hip_atomic_store(status + w, st.status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             atomicAdd(&counters->rk_attempts, (unsigned long long)st.steps);
             atomicAdd(&counters->newton_iters, (unsigned long long)st.newton_iters);
             atomicAdd(&counters->factorisations, (unsigned long long)st.nlu);
             atomicAdd(&counters->completed_solves, 1ULL);
             if (st.status != 0) atomicAdd(&counters->failed_solves, 1ULL);
         }
+        // the join of the lane branch above must be a block of its own: merged with the loop's latch (where `continue`,
+        // `break` and the end of the body meet) it would make the loop's exit look divergent to the compiler
+        __builtin_amdgcn_wave_barrier();
     }
     if (split && lane == 0) atomicAdd(&counters->wave_split, 1ULL);
 }
@@ -90,12 +185,24 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
 // a live particle with an experiment nobody solved gets NaN and is counted, so stale flows can never pass as a result.
 __global__ void meth_particle_loglike_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
                                              const double *__restrict__ flows, const int *__restrict__ status,
-                                             const uint8_t *__restrict__ p0mask, SweepCounters *__restrict__ counters,
+                                             uint8_t *__restrict__ p0mask, SweepCounters *__restrict__ counters,
                                              double *__restrict__ lk) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     if (p0mask && p0mask[p] == 0) {   // masked proposal: nothing was solved, the accept kernel keeps lk1
         lk[p] = __longlong_as_double(0x7ff8000000000000LL);
+        return;
+    }
+    int unsolved = 0, cancelled = 0;
+    for (int e = 0; e < m.n_data; ++e) {
+        const int st = status[p * m.n_data + e];
+        unsolved += (st == kStatusUnsolved);
+        cancelled += (st == kStatusCancelled);
+    }
+    if (cancelled) {   // rejected for certain before all of its experiments were solved: its logL is never formed (and not
+        lk[p] = __longlong_as_double(0x7ff8000000000000LL);   // needed: the accept kernel sees the flag and keeps p_filt, lk1)
+        if (p0mask) p0mask[p] = 2;
+        if (unsolved) atomicAdd(&counters->unsolved_items, (unsigned long long)unsolved);   // cannot happen: every item is dequeued
         return;
     }
     double sigma = m.sigma_fixed;
@@ -108,14 +215,10 @@ __global__ void meth_particle_loglike_kernel(MethModel m, const double *__restri
     double total = 0.0;
     for (int i = 0; i < 5; ++i) {
         double acc = 0.0;
-        for (int e = 0; e < m.n_data; ++e) {
-            const double d = flows[(p * m.n_data + e) * 5 + i] - m.obs[i * m.n_data + e];
-            acc += d * d;
-        }
-        total += c * acc - l;
+        for (int e = 0; e < m.n_data; ++e)
+            acc = meth_acc_step(acc, flows[(p * m.n_data + e) * 5 + i] - m.obs[i * m.n_data + e]);
+        total = meth_loglike_step(total, c, acc, l);
     }
-    int unsolved = 0;
-    for (int e = 0; e < m.n_data; ++e) unsolved += (status[p * m.n_data + e] == kStatusUnsolved);
     if (unsolved) {
         atomicAdd(&counters->unsolved_items, (unsigned long long)unsolved);
         total = __longlong_as_double(0x7ff8000000000000LL);
@@ -128,8 +231,23 @@ __global__ void meth_particle_loglike_kernel(MethModel m, const double *__restri
 __global__ void __launch_bounds__(256)
 generic_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int64_t stride, int64_t n, int d,
                        double *__restrict__ prop, int64_t pstride, uint8_t *__restrict__ p0_out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && mh.reject_out) {   // what the early-rejection bound of this sweep's solves reads
+        RejectArgs r;
+        r.lk1 = mh.reject_lk1;
+        r.rr = mh.rr;
+        r.pratio = mh.pratio;
+        r.gamma = mh.gamma;
+        r.seed = mh.seed;
+        r.stream = mh.stream;
+        r.global_offset = mh.global_offset;
+        r.device_rng = mh.device_rng;
+        r.prior_mode = mh.prior_mode;
+        *mh.reject_out = r;
+    }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (mh.pending_sums)   // user model with early rejection: none of this sweep's items has finished yet (NaN = pending)
+        for (int k = 0; k < mh.pending_n_ex; ++k) mh.pending_sums[(int64_t)k * n + p] = __longlong_as_double(0x7ff8000000000000LL);
     double z[SMC_MAX_DIM], g[SMC_MAX_DIM];
     if (mh.device_rng) {
         const uint64_t gi = (uint64_t)(mh.global_offset + p);
@@ -182,8 +300,9 @@ generic_accept_kernel(MHParams mh, const double *__restrict__ prop, int64_t pstr
     unsigned long long acc_now = 0, acc_ever = 0;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const bool masked = p0_in[p] == 0;
+        const bool cancelled = p0_in[p] == 2;   // methanation: rejected for certain before all experiments were solved
         const double lk1 = lk_io[p];
-        const double lk2 = masked ? lk1 : lk2_arr[p];
+        const double lk2 = (masked || cancelled) ? lk1 : lk2_arr[p];
         const double p0 = masked ? 0.0 : 1.0;
         double rr;
         if (mh.device_rng) {
@@ -195,7 +314,7 @@ generic_accept_kernel(MHParams mh, const double *__restrict__ prop, int64_t pstr
         double pp = exp((lk2 - lk1) * mh.gamma);
         if (mh.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * mh.pratio[p];
         if (mh.prior_mode != SMC_PRIOR_MODE_RATIO) pp = pp * p0;
-        const double r = (pp >= rr) ? 1.0 : 0.0, nr = 1.0 - r;
+        const double r = (!cancelled && pp >= rr) ? 1.0 : 0.0, nr = 1.0 - r;
         for (int c = 0; c < d; ++c) {
             const double th = prop[c * pstride + p], f = filt[c * fstride + p];
             filt[c * fstride + p] = __dadd_rn(__dmul_rn(th, r), __dmul_rn(f, nr));
@@ -226,7 +345,7 @@ generic_accept_kernel(MHParams mh, const double *__restrict__ prop, int64_t pstr
     }
 }
 
-static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask) {
+static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask, bool reject) {
     const MethModel &m = ctx->meth;
     int64_t nwaves = (int64_t)ctx->cu_count * 4;
     if (nwaves > n * m.n_data) nwaves = n * m.n_data;
@@ -240,19 +359,20 @@ static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int
         ctx->launch_failed = true;
         return;
     }
-    const int64_t *list = nullptr;
+    const int64_t *live = nullptr;
     if (p0mask) {
-        hipLaunchKernelGGL(meth_worklist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p0mask, n,
-                           m.n_data, ctx->d_mwork, ctx->d_queue);
-        list = ctx->d_mwork;
+        hipLaunchKernelGGL(meth_livelist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p0mask, n,
+                           ctx->d_mwork, ctx->d_queue);
+        live = ctx->d_mwork;
     }
     hipLaunchKernelGGL(meth_particles_dae_kernel, dim3((unsigned)nwaves), dim3(64), kLdsDoubles * sizeof(double), ctx->stream,
-                       m, theta, stride, n, list, ctx->d_mflows, ctx->d_mstatus, ctx->d_counters, ctx->d_queue);
+                       m, theta, stride, n, live, ctx->d_mflows, ctx->d_mstatus, reject ? ctx->d_reject : nullptr,
+                       ctx->d_counters, ctx->d_queue);
 }
 
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk) {
     if (n <= 0) return;
-    launch_solves(ctx, theta, stride, n, nullptr);
+    launch_solves(ctx, theta, stride, n, nullptr, false);
     if (ctx->launch_failed) return;
     hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
                        theta, stride, n, ctx->d_mflows, ctx->d_mstatus, nullptr, ctx->d_counters, lk);
@@ -275,11 +395,20 @@ void launch_generic_accept(smc_ctx *ctx, int64_t n, const MHParams &mh, const do
                        dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);
 }
 
-void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh) {
+void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     if (n <= 0) return;
     ParticleSet &P = ctx->set[SMC_SET_PRED];
+    // exact early rejection: off while the proposals' likelihoods are captured for inspection (they would be incomplete),
+    // and for data sets with more experiments than a wave has lanes (the bound looks at one experiment per lane)
+    const bool reject = ctx->early_reject != 0 && ctx->debug_capture == 0 && mh_in.gamma > 0.0 && ctx->d_reject &&
+                        ctx->meth.n_data <= kWave;
+    MHParams mh = mh_in;
+    if (reject) {
+        mh.reject_out = ctx->d_reject;
+        mh.reject_lk1 = ctx->set[SMC_SET_FILT].lk;
+    }
     launch_generic_propose(ctx, n, mh);
-    launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0);
+    launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0, reject);
     if (ctx->launch_failed) return;
     hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
                        P.theta, P.stride, n, ctx->d_mflows, ctx->d_mstatus, ctx->d_p0, ctx->d_counters, ctx->d_mlk2);

@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "mm_rk45.h"
+#include "solve_sched.h"
 #include "philox.h"
 #include "prior.h"
 #include "smc_internal.h"
@@ -146,33 +147,10 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// solve: persistent waves, lane-level dynamic scheduling
+// solve: persistent waves, lane-level dynamic scheduling (solve_sched.h) of Michaelis-Menten items
 // ---------------------------------------------------------------------------------------------
 constexpr int kSolveBlock = 256;   // 4 waves
-#ifndef SMC_CHUNK
-#define SMC_CHUNK 128
-#endif
-constexpr int kChunk = SMC_CHUNK;    // items per global dequeue (2 per lane)
-static_assert(kChunk % 64 == 0, "the chunk dequeue adds kChunk / 64 per lane");
-#ifndef SMC_REFILL_AT
-#define SMC_REFILL_AT 24
-#endif
-constexpr int kRefillAt = SMC_REFILL_AT;   // idle lanes that make a wave look at its pool (and refill it when it is empty)
-#ifndef SMC_POOL_FREE
-#define SMC_POOL_FREE 48
-#endif
-constexpr int kPoolRefillFree = SMC_POOL_FREE;   // free pool slots that trigger the start of that many new items
-constexpr int kPoolWords = 15;            // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer
-
-#ifndef SMC_STIFF_PER_CHUNK
-#define SMC_STIFF_PER_CHUNK 16
-#endif
-// Entries of the stiff list a wave takes with one dequeue.  Fewer than a full wave on purpose: the long solves spread over
-// many waves (12 000 list items of a 10^6-particle prior sweep -> 750 waves), each of which fills its other lanes with
-// ordinary items, so that at the end of the sweep a wave rarely holds two survivors and can run its last one on
-// wave-uniform operands (the tail below).
-constexpr int kStiffPerChunk = SMC_STIFF_PER_CHUNK;
-static_assert(kStiffPerChunk >= 1 && kStiffPerChunk <= 64, "a stiff chunk is started by one wave at once");
+constexpr int kPoolWords = 15;     // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer
 
 struct SolveArgs {              // everything the attempt loops do not touch stays behind a pointer (RejectArgs, StiffList)
     const double *theta;        // SoA rows: Vmax at [p], Km at [stride + p], sigma at [2*stride + p]
@@ -244,26 +222,134 @@ __device__ __forceinline__ bool mm_certainly_rejected(const MMModel &mm, const S
     if (r.prior_mode != SMC_PRIOR_MODE_MASK) pp = pp * r.pratio[p];
     return pp < rr * (1.0 - 1e-12);   // the margin covers a last-bit non-monotonicity of exp
 }
-constexpr int kRejectCheckEvery = 512;   // attempts between two looks at the bound (a look costs about five attempts)
 
-// value of lane `src` (wave-uniform index) in every lane, as a scalar
-__device__ __forceinline__ double lane_value(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
+// What solve_sched.h needs to know about a Michaelis-Menten item (see the list at the top of that file).
+// EXACT: parity mode (smc_set_exact_pow) - the step controller's power is the correctly rounded pow(x, -0.2), mm_rk45.h.
+template <bool WRITE_PRED, bool EXACT>
+struct MMOps {
+    struct Item {
+        MMItem s;
+        int64_t out_idx;    // e*n + p
+        double *pred;       // WRITE_PRED: where its predictions go
+    };
+    static constexpr int kPoolWords = smc::kPoolWords;
+    const MMModel &mm;
+    const SolveArgs &a;
+    const double2 *s_tp;    // LDS: n_ex rows of n_t + 1 (time, P_obs) pairs (mm_rk45.h)
+    const double *s_S0;     // LDS
+    long long n;
+    int n_ex, n_t;
+    const int32_t *list;
+    unsigned n_list;
+    double rtol, atol;
+
+    __device__ __forceinline__ int start(long long p, int e, bool from_list, Item &nb) const {
+        nb.out_idx = (int64_t)e * a.n + p;
+        nb.pred = nullptr;
+        const bool masked = a.p0 && a.p0[p] == 0;        // masked proposal: lk2 == lk1, no solve
+        const double Vmax = a.theta[p], Km = a.theta[a.stride + p];
+        const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
+        // index-ordered pass: a particle of the stiff list has been handed out already
+        if (!from_list && list && !masked && mm_is_stiff(Vmax, Km)) return kStartSkipped;
+        if (masked || sigma <= 0.0) {                    // sigma <= 0: -inf without solving (:53-54)
+            publish_item(a, nb.out_idx, 0.0, 0);
+            if (WRITE_PRED) {
+                double *pp = a.pred + ((size_t)p * n_ex + e) * n_t;
+                for (int i = 0; i < n_t; ++i) pp[i] = quiet_nan();
+            }
+            return kStartDone;
+        }
+        if (WRITE_PRED) nb.pred = a.pred + ((size_t)p * n_ex + e) * n_t;
+        if (mm_item_begin<WRITE_PRED, EXACT>(nb.s, Vmax, Km, s_S0[e], s_tp, mm_table_row(e, n_t), n_t, rtol, atol, nb.pred))
+            return kStartStarted;
+        const bool ok = (nb.s.i_out == n_t);             // nothing to integrate: finished at once
+        publish_item(a, nb.out_idx, ok ? nb.s.sum_r2 : quiet_nan(), ok ? 0 : kInfoFailed);
+        return kStartDone;
+    }
+    // word-major slots so that lanes reading or writing consecutive slots hit consecutive banks
+    __device__ __forceinline__ void pack(const Item &nb, double *slot) const {
+        slot[0 * kWave] = nb.s.negVmax;
+        slot[1 * kWave] = nb.s.Km;
+        slot[2 * kWave] = nb.s.S0;
+        slot[3 * kWave] = nb.s.t;
+        slot[4 * kWave] = nb.s.y;
+        slot[5 * kWave] = nb.s.f;
+        slot[6 * kWave] = nb.s.h_abs;
+        slot[7 * kWave] = nb.s.min_step;
+        slot[8 * kWave] = nb.s.t_bound;
+        slot[9 * kWave] = nb.s.t_next;
+        slot[10 * kWave] = nb.s.sum_r2;
+        slot[11 * kWave] = __hiloint2double(nb.s.i_out, nb.s.t_off);
+        slot[12 * kWave] = __hiloint2double((int)nb.s.rejected, nb.s.attempts);
+        slot[13 * kWave] = __longlong_as_double((long long)nb.out_idx);
+        if (WRITE_PRED) slot[14 * kWave] = __longlong_as_double((long long)nb.pred);
+    }
+    __device__ __forceinline__ void unpack(Item &it, const double *slot) const {
+        it.s.negVmax = slot[0 * kWave];
+        it.s.Km = slot[1 * kWave];
+        it.s.S0 = slot[2 * kWave];
+        it.s.t = slot[3 * kWave];
+        it.s.y = slot[4 * kWave];
+        it.s.f = slot[5 * kWave];
+        it.s.h_abs = slot[6 * kWave];
+        it.s.min_step = slot[7 * kWave];
+        it.s.t_bound = slot[8 * kWave];
+        it.s.t_next = slot[9 * kWave];
+        it.s.sum_r2 = slot[10 * kWave];
+        const double w11 = slot[11 * kWave], w12 = slot[12 * kWave];
+        it.s.t_off = __double2loint(w11);
+        it.s.i_out = __double2hiint(w11);
+        it.s.attempts = __double2loint(w12);
+        it.s.rejected = __double2hiint(w12) != 0;
+        it.out_idx = (int64_t)__double_as_longlong(slot[13 * kWave]);
+        it.pred = WRITE_PRED ? (double *)__double_as_longlong(slot[14 * kWave]) : nullptr;
+    }
+    __device__ __forceinline__ int attempt(Item &it) const {
+        return mm_item_attempt<WRITE_PRED, kDivLean6, EXACT>(it.s, s_tp, n_t, rtol, atol, it.pred);
+    }
+    __device__ __forceinline__ void finish(Item &it, int st) const {
+        const bool ok = (st == 1) && (it.s.i_out == n_t);
+        publish_item(a, it.out_idx, ok ? it.s.sum_r2 : quiet_nan(), it.s.attempts | (ok ? 0 : kInfoFailed));
+        if (WRITE_PRED && !ok)
+            for (int i = it.s.i_out; i < n_t; ++i) it.pred[i] = quiet_nan();
+    }
+    __device__ __forceinline__ Item broadcast(const Item &it, int src) const {
+        Item u;
+        u.s.negVmax = lane_value(it.s.negVmax, src);
+        u.s.Km = lane_value(it.s.Km, src);
+        u.s.S0 = lane_value(it.s.S0, src);
+        u.s.t = lane_value(it.s.t, src);
+        u.s.y = lane_value(it.s.y, src);
+        u.s.f = lane_value(it.s.f, src);
+        u.s.h_abs = lane_value(it.s.h_abs, src);
+        u.s.min_step = lane_value(it.s.min_step, src);
+        u.s.t_bound = lane_value(it.s.t_bound, src);
+        u.s.t_next = lane_value(it.s.t_next, src);
+        u.s.sum_r2 = lane_value(it.s.sum_r2, src);
+        u.s.t_off = __builtin_amdgcn_readlane(it.s.t_off, src);
+        u.s.i_out = __builtin_amdgcn_readlane(it.s.i_out, src);
+        u.s.attempts = __builtin_amdgcn_readlane(it.s.attempts, src);
+        u.s.rejected = __builtin_amdgcn_readlane((int)it.s.rejected, src) != 0;
+        u.out_idx = lane_value_ll(it.out_idx, src);
+        u.pred = WRITE_PRED ? (double *)lane_value_ll((long long)it.pred, src) : nullptr;
+        return u;
+    }
+    __device__ __forceinline__ bool reject_enabled() const { return a.rej != nullptr; }
+    __device__ __forceinline__ bool certainly_rejected(const Item &it) const {
+        const int e_self = (int)(it.out_idx / a.n);
+        return mm_certainly_rejected(mm, a, it.out_idx - (int64_t)e_self * a.n, e_self, it.s.sum_r2);
+    }
+    __device__ __forceinline__ void cancel(Item &it) const {
+        publish_item(a, it.out_idx, kSumCancelled, it.s.attempts | kInfoCancelled);
+    }
+};
 
 #ifdef SMC_SOLVE_WAVES   // A/B knob: waves per SIMD the register allocation is limited to
 #define SMC_SOLVE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SMC_SOLVE_WAVES, SMC_SOLVE_WAVES)))
 #else
 #define SMC_SOLVE_WAVES_ATTR
 #endif
-#ifdef SMC_ISA_MARKS   // analysis builds only (tools/isa_blocks.py): names the loops in the `hipcc -S` listing
-#define SMC_ISA_MARK(name) asm volatile("; MARK " name)
-#else
-#define SMC_ISA_MARK(name)
-#endif
-template <bool WRITE_PRED>
+template <bool WRITE_PRED, bool EXACT>
 __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_kernel(MMModel mm, SolveArgs a) {
     extern __shared__ double2 smem_tp[];
     const int n_ex = mm.n_ex, n_t = mm.n_t;
@@ -272,312 +358,11 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     mm_table_fill(s_tp, mm.t, mm.P_obs, n_ex, n_t, threadIdx.x, blockDim.x);
     if (threadIdx.x < n_ex) s_S0[threadIdx.x] = mm.S0[threadIdx.x];
     __syncthreads();
-    // The wave's pool of STARTED items (mm_item_begin done, no attempt yet): a ring of 64 slots in LDS, word-major so that
-    // lanes reading or writing consecutive slots hit consecutive banks.  Starting items and running them are decoupled:
-    // items are started 48 or more at a time by lanes 0 .. take-1 whatever those lanes are running (the start-up code -
-    // index arithmetic, three loads, select_initial_step with its nine IEEE divisions - used to run with 24 of 64 lanes
-    // active), and a lane that finishes takes its next item from the pool after at most a few attempts of waiting.
+    // the wave's pool of STARTED items (solve_sched.h): a ring of 64 slots of kPoolWords words
     double *s_pool = s_S0 + ((n_ex + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kPoolWords * kWave);
-
-    // Queue space: first the stiff list, n_ex passes over it in chunks of kChunk indices of which the first kStiffPerChunk
-    // are list entries (so that the chunk arithmetic below stays in units of kChunk), then the index-ordered items in groups
-    // of 64 particles x n_ex experiments; the last group may be partial.
-    const unsigned long long n_blk = (unsigned long long)((a.n + kWave - 1) / kWave);
     const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)*a.stiff_count) : 0u;
-    const unsigned stiff_cpe = (n_stiff + kStiffPerChunk - 1) / kStiffPerChunk;          // chunks per experiment
-    const unsigned long long q_stiff_end = (unsigned long long)stiff_cpe * n_ex * kChunk;
-    const unsigned long long n_items = q_stiff_end + n_blk * kWave * n_ex;
-    const int lane = threadIdx.x & (kWave - 1);
-    const double rtol = mm.rtol, atol = mm.atol;
-
-    MMItem it;
-    it.attempts = 0;
-    bool live = false;              // this lane holds a running item
-    int64_t out_idx = 0;            // e*n + p of the running item
-    double *pred_item = nullptr;
-    // Loop control lives in SGPRs (the chunk bounds come back from the atomic through v_readfirstlane, n_idle from a
-    // ballot): every branch of the scheduling logic is a scalar branch.  In round 1 q_lo / q_hi travelled through a
-    // __shfl, the compiler had to treat `q_lo == q_hi` and `drained` as divergent and wrapped the whole loop in exec-mask
-    // bookkeeping: 0.19 us per iteration on top of the 0.41 us of an attempt for a wave that runs alone (the stragglers of
-    // the early tempering steps), measured with tools/tail_latency.py.
-    unsigned long long q_lo = 0, q_hi = 0;  // the wave's current chunk
-    unsigned long long q_blk = 0;           // regular chunk: block of 64 particles of the 64-item group of its first item ...
-    unsigned long long q_grp = 0;           // ... that group
-    int q_e = 0;                            // ... and experiment (one division per chunk, none per hand-out)
-    unsigned q_list = 0;                    // stiff chunk: list index of its first entry
-    bool q_stiff = false;
-    bool drained = false;                   // the global queue is empty
-
-    int pool_head = 0, pool_count = 0;      // the ring of started items: slots [head, head + count) mod 64 (wave-uniform)
-
-    for (;;) {
-        // ---- start new items into the pool ------------------------------------------------------------------
-        if (!drained && kWave - pool_count >= kPoolRefillFree) {
-            if (q_lo == q_hi) {  // next chunk: one atomic per wave and kChunk indices
-                // The first active lane adds kChunk, every other lane adds 0, and the first lane's return value is the
-                // start of the chunk: correct whether the compiler's atomic optimiser folds the 64 lane atomics into
-                // one (it does) or not - round 2's form (every lane adds kChunk / 64) was correct only with it.  And no
-                // `if (lane == 0)` around the atomic: the compiler may split such a branch from the v_readfirstlane
-                // that follows it and let the other lanes run ahead with b = 0 (profiles/r02_k8_dequeue_hang_isa.md).
-                const unsigned long long b = atomicAdd(a.queue, lane == 0 ? (unsigned long long)kChunk : 0ull);
-                const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-                const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
-                q_lo = ((unsigned long long)b_hi << 32) | b_lo;
-                if (q_lo >= n_items) {
-                    drained = true;
-                    q_lo = q_hi = 0;
-                } else if (q_lo < q_stiff_end) {
-                    q_stiff = true;
-                    const unsigned c = (unsigned)(q_lo / kChunk);
-                    q_e = (int)(c / stiff_cpe);
-                    q_list = (c - (unsigned)q_e * stiff_cpe) * kStiffPerChunk;
-                    const unsigned left = n_stiff - q_list;
-                    q_hi = q_lo + (left < (unsigned)kStiffPerChunk ? left : (unsigned)kStiffPerChunk);
-                } else {
-                    q_stiff = false;
-                    q_hi = (q_lo + kChunk < n_items) ? q_lo + kChunk : n_items;
-                    q_grp = (q_lo - q_stiff_end) >> 6;
-                    q_e = (int)(q_grp / n_blk);          // experiment-major: see the item order note above
-                    q_blk = q_grp - (unsigned long long)q_e * n_blk;
-                }
-            }
-            if (!drained) {
-                const unsigned long long avail = q_hi - q_lo;
-                const int free_slots = kWave - pool_count;
-                const int take = (unsigned long long)free_slots < avail ? free_slots : (int)avail;
-                bool started = false;               // this lane's new item needs attempts: it goes into the pool
-                MMItem nb;
-                int64_t nb_idx = 0;
-                double *nb_pred = nullptr;
-                if (lane < take) {
-                    int64_t p;
-                    int e = q_e;
-                    if (q_stiff) {
-                        p = a.stiff_list[q_list + (unsigned)(q_lo % kChunk) + (unsigned)lane];
-                    } else {
-                        const unsigned long long item = q_lo - q_stiff_end + lane;
-                        // 64-item group = (experiment, block of 64 particles); a chunk spans kChunk / 64 + 1 groups at most
-                        unsigned long long blk = q_blk + ((item >> 6) - q_grp);
-#pragma unroll
-                        for (int w = 0; w < kChunk / 64 + 1; ++w)
-                            if (blk >= n_blk) { blk -= n_blk; ++e; }
-                        p = (int64_t)blk * kWave + (int64_t)(item & 63);
-                    }
-                    if (p < a.n) {
-                        nb_idx = (int64_t)e * a.n + p;
-                        const bool masked = a.p0 && a.p0[p] == 0;        // masked proposal: lk2 == lk1, no solve
-                        const double Vmax = a.theta[p], Km = a.theta[a.stride + p];
-                        const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
-                        // index-ordered pass: a particle of the stiff list has been handed out already
-                        const bool listed = !q_stiff && a.stiff_list && !masked && mm_is_stiff(Vmax, Km);
-                        const bool run = !masked && !(sigma <= 0.0);     // sigma <= 0: -inf without solving (:53-54)
-                        if (listed) {
-                        } else if (run) {
-                            if (WRITE_PRED) nb_pred = a.pred + ((size_t)p * n_ex + e) * n_t;
-                            started = mm_item_begin<WRITE_PRED>(nb, Vmax, Km, s_S0[e], s_tp, mm_table_row(e, n_t), n_t, rtol,
-                                                                atol, nb_pred);
-                            if (!started) {  // nothing to integrate: finished at once
-                                const bool ok = (nb.i_out == n_t);
-                                publish_item(a, nb_idx, ok ? nb.sum_r2 : quiet_nan(), ok ? 0 : kInfoFailed);
-                            }
-                        } else {
-                            publish_item(a, nb_idx, 0.0, 0);
-                            if (WRITE_PRED) {
-                                double *pp = a.pred + ((size_t)p * n_ex + e) * n_t;
-                                for (int i = 0; i < n_t; ++i) pp[i] = quiet_nan();
-                            }
-                        }
-                    }
-                }
-                const unsigned long long started_mask = __ballot(started);
-                if (started) {
-                    const int r = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(started_mask >> 32),
-                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)started_mask, 0u));
-                    double *slot = s_pool + ((pool_head + pool_count + r) & (kWave - 1));
-                    slot[0 * kWave] = nb.negVmax;
-                    slot[1 * kWave] = nb.Km;
-                    slot[2 * kWave] = nb.S0;
-                    slot[3 * kWave] = nb.t;
-                    slot[4 * kWave] = nb.y;
-                    slot[5 * kWave] = nb.f;
-                    slot[6 * kWave] = nb.h_abs;
-                    slot[7 * kWave] = nb.min_step;
-                    slot[8 * kWave] = nb.t_bound;
-                    slot[9 * kWave] = nb.t_next;
-                    slot[10 * kWave] = nb.sum_r2;
-                    slot[11 * kWave] = __hiloint2double(nb.i_out, nb.t_off);
-                    slot[12 * kWave] = __hiloint2double((int)nb.rejected, nb.attempts);
-                    slot[13 * kWave] = __longlong_as_double((long long)nb_idx);
-                    if (WRITE_PRED) slot[14 * kWave] = __longlong_as_double((long long)nb_pred);
-                }
-                pool_count += __popcll(started_mask);
-                q_lo += take;
-            }
-        }
-        // ---- idle lanes take started items from the pool (LDS operations of one wave execute in order) ------------
-        __builtin_amdgcn_wave_barrier();
-        {
-            const unsigned long long idle_mask = ~__ballot(live);
-            const int n_idle = __popcll(idle_mask);
-            if (pool_count > 0 && n_idle > 0) {
-                const int k = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle_mask >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned)idle_mask, 0u));
-                const int n_take = n_idle < pool_count ? n_idle : pool_count;
-                if (!live && k < n_take) {
-                    const double *slot = s_pool + ((pool_head + k) & (kWave - 1));
-                    it.negVmax = slot[0 * kWave];
-                    it.Km = slot[1 * kWave];
-                    it.S0 = slot[2 * kWave];
-                    it.t = slot[3 * kWave];
-                    it.y = slot[4 * kWave];
-                    it.f = slot[5 * kWave];
-                    it.h_abs = slot[6 * kWave];
-                    it.min_step = slot[7 * kWave];
-                    it.t_bound = slot[8 * kWave];
-                    it.t_next = slot[9 * kWave];
-                    it.sum_r2 = slot[10 * kWave];
-                    const double w11 = slot[11 * kWave], w12 = slot[12 * kWave];
-                    it.t_off = __double2loint(w11);
-                    it.i_out = __double2hiint(w11);
-                    it.attempts = __double2loint(w12);
-                    it.rejected = __double2hiint(w12) != 0;
-                    out_idx = (int64_t)__double_as_longlong(slot[13 * kWave]);
-                    if (WRITE_PRED) pred_item = (double *)__double_as_longlong(slot[14 * kWave]);
-                    live = true;
-                }
-                pool_head = (pool_head + n_take) & (kWave - 1);
-                pool_count -= n_take;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (!drained && pool_count == 0 && __ballot(live) == 0ull) continue;   // every started item was done at once: start more
-        if (drained && pool_count == 0) {
-            // tail: no item is left to hand out or to take from the pool.  What remains are the long serial chains of stiff items.
-            // A wave that holds exactly ONE of them (the usual case: they are 1 in 10^3 .. 10^4 items) runs it with the
-            // item's state broadcast to the whole wave through v_readlane: every operand is then wave-uniform, the
-            // compiler turns the accept / reject / output branches into scalar branches and drops the per-lane selects,
-            // and the attempt takes 0.42 instead of 0.52 us (tools/attempt_probe.hip: the same solve with uniform and
-            // with per-lane operands; tools/tail_latency.py on the product kernel).  The arithmetic is the same
-            // function on the same operands, so the result is bit-identical.
-            for (;;) {
-                const unsigned long long tail_mask = __ballot(live);
-                const int n_live = __popcll(tail_mask);
-                if (n_live == 0) break;
-                if (n_live == 1) {
-                    const int src = __ffsll((unsigned long long)tail_mask) - 1;
-                    MMItem u;
-                    u.negVmax = lane_value(it.negVmax, src);
-                    u.Km = lane_value(it.Km, src);
-                    u.S0 = lane_value(it.S0, src);
-                    u.t = lane_value(it.t, src);
-                    u.y = lane_value(it.y, src);
-                    u.f = lane_value(it.f, src);
-                    u.h_abs = lane_value(it.h_abs, src);
-                    u.min_step = lane_value(it.min_step, src);
-                    u.t_bound = lane_value(it.t_bound, src);
-                    u.t_next = lane_value(it.t_next, src);
-                    u.sum_r2 = lane_value(it.sum_r2, src);
-                    u.t_off = __builtin_amdgcn_readlane(it.t_off, src);
-                    u.i_out = __builtin_amdgcn_readlane(it.i_out, src);
-                    u.attempts = __builtin_amdgcn_readlane(it.attempts, src);
-                    u.rejected = __builtin_amdgcn_readlane((int)it.rejected, src) != 0;
-                    double *u_pred = nullptr;
-                    if (WRITE_PRED) {
-                        const unsigned long long pv = (unsigned long long)pred_item;
-                        u_pred = (double *)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(pv >> 32), src) << 32) |
-                                            (unsigned)__builtin_amdgcn_readlane((int)(unsigned)pv, src));
-                    }
-                    const int64_t u_idx = ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(out_idx >> 32), src) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)out_idx, src);
-                    const int u_e = (int)(u_idx / a.n);
-                    const int64_t u_p = u_idx - (int64_t)u_e * a.n;
-                    // The look at the bound sits in an outer loop so that the attempt loop itself stays the bare serial
-                    // chain: with the check inside it the compiler kept the check's operands live across every attempt
-                    // and reloaded spilled SGPRs in the loop (0.51 instead of 0.41 us per attempt, tools/tail_latency.py).
-                    int st = 0;
-                    bool cancelled = false;
-                    for (;;) {
-                        // first look at once.  Every lane evaluates the same bound on the same operands, but its atomic
-                        // loads are a source of divergence for the compiler: without the v_readfirstlane it wraps the
-                        // WHOLE attempt loop below in exec-mask control flow (s_and_saveexec per branch, per-lane selects)
-                        // instead of scalar branches - that is how the uniform tail lost a tenth of a microsecond per
-                        // attempt when early rejection went in (tools/isa_blocks.py on the listing: 11 saveexec / 0
-                        // s_cbranch_vcc with the bare call, 0 / 8 with the broadcast).
-                        if (a.rej && __builtin_amdgcn_readfirstlane((int)mm_certainly_rejected(mm, a, u_p, u_e, u.sum_r2))) {
-                            cancelled = true;
-                            break;
-                        }
-                        int budget = kRejectCheckEvery;
-                        do {
-                            SMC_ISA_MARK("uniform_tail_attempt");
-                            st = mm_item_attempt<WRITE_PRED>(u, s_tp, n_t, rtol, atol, u_pred);
-                        } while (st == 0 && --budget > 0);
-                        if (st != 0) break;
-                    }
-                    // Every lane holds the same result and stores it to the same address (u_idx is a scalar): one wave-wide
-                    // store of 64 identical values instead of an `if (lane == src)` - a divergent branch whose join would
-                    // be this loop's exit block, which is exactly what makes the compiler's uniformity analysis call the
-                    // whole tail loop, with its ballots and v_readlanes, a cycle with a divergent exit
-                    // (tests/test_k8_uniform_control.py checks that it does not).
-                    if (cancelled) {
-                        publish_item(a, u_idx, kSumCancelled, u.attempts | kInfoCancelled);
-                    } else {
-                        const bool ok = (st == 1) && (u.i_out == n_t);
-                        publish_item(a, u_idx, ok ? u.sum_r2 : quiet_nan(), u.attempts | (ok ? 0 : kInfoFailed));
-                        if (WRITE_PRED && !ok)
-                            for (int i = u.i_out; i < n_t; ++i) u_pred[i] = quiet_nan();
-                    }
-                    live = false;
-                    break;
-                }
-                // several stiff items in this wave: per-lane attempts until one of them is done, then look again
-                int n_now, since_check = kRejectCheckEvery;     // first look at the bound at once
-                do {
-                    if (live) {
-                        if (a.rej && ++since_check > kRejectCheckEvery) {
-                            since_check = 0;
-                            const int e_self = (int)(out_idx / a.n);
-                            if (mm_certainly_rejected(mm, a, out_idx - (int64_t)e_self * a.n, e_self, it.sum_r2)) {
-                                publish_item(a, out_idx, kSumCancelled, it.attempts | kInfoCancelled);
-                                live = false;
-                            }
-                        }
-                    }
-                    if (live) {
-                        SMC_ISA_MARK("lane_tail_attempt");
-                        const int st = mm_item_attempt<WRITE_PRED>(it, s_tp, n_t, rtol, atol, pred_item);
-                        if (st != 0) {
-                            const bool ok = (st == 1) && (it.i_out == n_t);
-                            publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), it.attempts | (ok ? 0 : kInfoFailed));
-                            if (WRITE_PRED && !ok)
-                                for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
-                            live = false;
-                        }
-                    }
-                    n_now = __popcll(__ballot(live));
-                } while (n_now == n_live);
-            }
-            break;
-        }
-        // attempts of the live lanes until kRefillAt lanes are idle (they then take items from the pool, which is refilled
-        // above when it runs low): a tight inner loop (item state stays in its registers, one ballot and one scalar branch
-        // per attempt) - the scheduling logic above runs once per hand-out, not once per attempt
-        int idle_now;
-        do {
-            SMC_ISA_MARK("bulk_attempt");
-            if (live) {
-                const int st = mm_item_attempt<WRITE_PRED>(it, s_tp, n_t, rtol, atol, pred_item);
-                if (st != 0) {
-                    const bool ok = (st == 1) && (it.i_out == n_t);
-                    publish_item(a, out_idx, ok ? it.sum_r2 : quiet_nan(), it.attempts | (ok ? 0 : kInfoFailed));
-                    if (WRITE_PRED && !ok)
-                        for (int i = it.i_out; i < n_t; ++i) pred_item[i] = quiet_nan();
-                    live = false;
-                }
-            }
-            idle_now = kWave - __popcll(__ballot(live));
-        } while (idle_now < kRefillAt);
-    }
+    MMOps<WRITE_PRED, EXACT> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff, mm.rtol, mm.atol};
+    solve_persistent(ops, a.queue, s_pool);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -749,14 +534,17 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.stiff_count = sl.count;
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
+    const bool exact = ctx->exact_pow != 0;
+    void (*kern)(MMModel, SolveArgs) = pred ? (exact ? mm_solve_kernel<true, true> : mm_solve_kernel<true, false>)
+                                            : (exact ? mm_solve_kernel<false, true> : mm_solve_kernel<false, false>);
     if (lds > 48 * 1024 && !ctx->solve_lds_raised) {
         // the largest data set (16 x 256) needs 66 + 30 KB of the CU's 160 KB: above the default dynamic limit.  The
         // attribute belongs to the (function, device) pair, so the flag lives in the context, not in the process.
-        const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&mm_solve_kernel<false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e1 != hipSuccess || e2 != hipSuccess) {
+        hipError_t e = hipSuccess;
+        for (const void *f : {reinterpret_cast<const void *>(&mm_solve_kernel<true, true>), reinterpret_cast<const void *>(&mm_solve_kernel<true, false>),
+                              reinterpret_cast<const void *>(&mm_solve_kernel<false, true>), reinterpret_cast<const void *>(&mm_solve_kernel<false, false>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) {
             smc_fail(ctx, "mm_solve_kernel: raising the dynamic LDS limit failed (hipFuncSetAttribute)");
             ctx->launch_failed = true;
             return;
@@ -771,10 +559,7 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     ScopedTimer tm(ctx, SMC_T_SOLVE);
-    if (pred)
-        hipLaunchKernelGGL((mm_solve_kernel<true>), dim3((unsigned)blocks), dim3(kSolveBlock), lds, ctx->stream, mm, a);
-    else
-        hipLaunchKernelGGL((mm_solve_kernel<false>), dim3((unsigned)blocks), dim3(kSolveBlock), lds, ctx->stream, mm, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSolveBlock), lds, ctx->stream, mm, a);
 }
 
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred) {
@@ -819,7 +604,7 @@ int query_solve_blocks_per_cu() {
         if (v >= 1) return v < 16 ? v : 16;     // beyond the hardware's wave slots the extra blocks only queue up
     }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false>, kSolveBlock, solve_lds_bytes(6, 40)) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false, false>, kSolveBlock, solve_lds_bytes(6, 40)) != hipSuccess || nb < 1)
         nb = 2;
     return nb;
 }

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pow_fifth_exact.h"
+
 namespace smc {
 
 // Dormand-Prince coefficients (rk.py:377-404), the same double literals Python evaluates.
@@ -121,24 +123,42 @@ __device__ __forceinline__ double quiet_nan() { return __longlong_as_double(0x7f
 // whose truncation error 0.09*rho^3 <= 2^-58.  Result within ~1.5 ulp - the same class as the
 // libm-vs-device pow difference it replaces (the CPU checker under tests keeps libm pow).  Arguments
 // outside the window are reduced first: x = m*2^e, e = 5q + r, m*2^r in [0.5, 16).
-__device__ __forceinline__ double pow_minus_fifth_core(double x) {
+// EXACT (parity mode, smc_set_exact_pow): the fast value is finished to the correctly rounded pow(x, -0.2) - the function
+// libm evaluates for SciPy, with the DOUBLE exponent -0.2 = -(1/5 + 1.1e-17) - by pow_fifth_exact.h: ~15 more operations
+// on the chain, so only the host-RNG (parity) mode pays for it.
+template <bool EXACT>
+__device__ __forceinline__ double pow_minus_fifth_core(double x, double ln_scale /* ln of x's scaling removed by the caller */) {
     const float lf = __builtin_amdgcn_logf((float)x);                 // v_log_f32: log2
     const double y = (double)__builtin_amdgcn_exp2f(-0.2f * lf);      // v_exp_f32
     const double y2 = y * y;
     const double y5 = (y2 * y2) * y;
     const double rho = fma(-x, y5, 1.0);
-    return fma(y * rho, fma(0.12, rho, 0.2), y);
+    const double y1 = fma(y * rho, fma(0.12, rho, 0.2), y);
+    if (!EXACT) return y1;
+    return pow_minus_fifth_finish(x, y1, fma((double)lf, 0.6931471805599453, ln_scale));
 }
+template <bool EXACT = false>
 __device__ __forceinline__ double pow_minus_fifth(double x) {
     const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0xfffu;  // sign + biased exponent
-    if (__builtin_expect((e - 959u) < 128u, 1)) return pow_minus_fifth_core(x);   // 2^-64 <= x < 2^64
+    if (__builtin_expect((e - 959u) < 128u, 1)) return pow_minus_fifth_core<EXACT>(x, 0.0);   // 2^-64 <= x < 2^64
     if (!(x > 0.0)) return (x == 0.0) ? __longlong_as_double(0x7ff0000000000000LL) : quiet_nan();  // 0 -> inf
     if (x == __longlong_as_double(0x7ff0000000000000LL)) return 0.0;
     const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     const int ex = __builtin_amdgcn_frexp_exp(x);
     const int q = (ex + 1075) / 5 - 215;               // floor(ex / 5), ex in [-1073, 1024]
     const int r = ex - 5 * q;                          // 0..4
-    return ldexp(pow_minus_fifth_core(ldexp(m, r)), -q);
+    // x = (m 2^r) 2^(5q): the fifth root scales exactly; the 1.1e-17 excess of the double exponent sees the whole ln x
+    return ldexp(pow_minus_fifth_core<EXACT>(ldexp(m, r), (5 * q) * 0.6931471805599453), -q);
+}
+// x ** (1 / 5) of select_initial_step (common.py:130): the reciprocal of the fast inverse root, or (EXACT) the correctly
+// rounded pow(x, 0.2) with the double exponent
+template <bool EXACT>
+__device__ __forceinline__ double pow_plus_fifth(double x) {
+    const double y0 = 1.0 / pow_minus_fifth<false>(x);
+    if (!EXACT) return y0;
+    const unsigned e = ((unsigned)__double2hiint(x) >> 20) & 0xfffu;
+    if ((e - 959u) < 128u) return pow_plus_fifth_finish(x, y0, (double)__builtin_amdgcn_logf((float)x) * 0.6931471805599453);
+    return pow(x, 0.2);   // outside 2^-64 .. 2^64: the library routine (never on the path of a sane model)
 }
 
 // Live state of one lane's current item.  common.py:63-65: the RMS norm of a size-1 vector is
@@ -175,7 +195,7 @@ __device__ __forceinline__ void mm_table_fill(double2 *s_tp, const double *t, co
 // direction +1, order 4, max_step inf) and the head of the first _step_impl (rk.py:120-127).
 // Returns false when there is nothing to integrate (t0 == t_bound, base.py:181-187): all outputs
 // are then already accumulated.
-template <bool WRITE_PRED>
+template <bool WRITE_PRED, bool EXACT = false>
 __device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km, double S0, const double2 *s_tp,
                                               int t_off, int n_t, double rtol, double atol, double *pred) {
     it.negVmax = -Vmax;
@@ -206,7 +226,7 @@ __device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km
         if (d1 <= 1e-15 && d2 <= 1e-15)
             h1 = py_max(1e-6, h0 * 1e-3);
         else
-            h1 = 1.0 / pow_minus_fifth(0.01 / py_max(d1, d2));  // x ** (1/5), common.py:130
+            h1 = pow_plus_fifth<EXACT>(0.01 / py_max(d1, d2));  // x ** (1/5), common.py:130
         it.h_abs = py_min(py_min(100.0 * h0, h1), interval);
     }
     if (it.t == it.t_bound) {  // every t_eval <= t gets y
@@ -279,7 +299,7 @@ __device__ __forceinline__ void mm_dense_outputs(MMItem &it, const double2 *s_tp
 
 // One step attempt.  Returns 0 while the item is still running, 1 when it finished (t reached
 // t_bound), 2 when it failed (step size underflow, rk.py:133-134; SciPy status -1).
-template <bool WRITE_PRED, int DIV = kDivLean6>
+template <bool WRITE_PRED, int DIV = kDivLean6, bool EXACT = false>
 __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, int n_t, double rtol, double atol,
                                                double *pred) {
     // rk.py:133-134 TOO_SMALL_STEP (plus the hard attempt bound): tested together with the other rare
@@ -300,7 +320,7 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, 
     // Accept / reject is written with selects, not branches: on the serial chain of a stiff solve every
     // vector-compare -> scalar-branch round trip costs as much as several FP64 operations.  The one
     // branch below covers both the rare IEEE re-run and the dense output.
-    double pw = 0.9 * pow_minus_fifth(st.error_norm);
+    double pw = 0.9 * pow_minus_fifth<EXACT>(st.error_norm);
     bool accept = st.error_norm < 1.0;
     const bool redo = !(st.error_norm <= 1.7976931348623157e308);   // NaN / inf from the lean division
     const double t_old = t, y_old = y;
@@ -308,7 +328,7 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, 
         if (fail) return 2;
         if (redo) {
             st = rk_attempt_core<kDivIeee>(y, k0, h, negVmax, Km, rtol, atol);
-            pw = 0.9 * pow_minus_fifth(st.error_norm);
+            pw = 0.9 * pow_minus_fifth<EXACT>(st.error_norm);
             accept = st.error_norm < 1.0;
         }
         if (accept && it.t_next <= t_new) {

@@ -3,10 +3,17 @@
 // is serial by construction, so device-RNG mode uses a counter keyed by (seed, GLOBAL particle
 // index, stream, block): results do not depend on the number of GPUs or on the launch geometry.
 #pragma once
+#ifndef __HIPCC_RTC__       // hiprtc (user_model.hip hands it this file as an in-memory header) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace smc {
+
+#ifdef __HIPCC_RTC__        // hiprtc keeps its fixed-width integer types in a namespace of its own
+using uint32_t = unsigned int;
+using uint64_t = unsigned long long;
+#endif
 
 struct u32x4 {
     uint32_t x, y, z, w;

@@ -359,12 +359,13 @@ int smc_meth_sweep_counters(smc_ctx *c, int64_t out[4]) {
     return 0;
 }
 
-int smc_meth_sweep_check(smc_ctx *c, int64_t out[4]) {
+int smc_meth_sweep_check(smc_ctx *c, int64_t out[5]) {
     if (!c) return fail(nullptr, "NULL context");
     out[0] = (int64_t)c->h_counters->expected_solves;
     out[1] = (int64_t)c->h_counters->completed_solves;
     out[2] = (int64_t)c->h_counters->unsolved_items;
     out[3] = (int64_t)c->h_counters->wave_split;
+    out[4] = (int64_t)c->h_counters->cancelled_solves;
     return 0;
 }
 
@@ -383,6 +384,12 @@ int smc_meth_download_solves(smc_ctx *c, double *flows, int32_t *status, int64_t
 int smc_set_early_reject(smc_ctx *c, int enable) {
     if (!c) return fail(nullptr, "NULL context");
     c->early_reject = enable != 0;
+    return 0;
+}
+
+int smc_set_exact_pow(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    c->exact_pow = enable != 0;
     return 0;
 }
 
@@ -503,10 +510,11 @@ static int counters_end(smc_ctx *c) {
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->model_kind == 2) {   // every (particle, experiment) item the sweep asked for must have been solved exactly once
         const SweepCounters &k = *c->h_counters;
-        if (k.completed_solves != k.expected_solves || k.unsolved_items != 0 || k.wave_split != 0) {
-            char buf[256];
-            snprintf(buf, sizeof buf, "methanation sweep incomplete: %llu of %llu DAE solves finished, %llu live items unsolved, "
-                     "%llu waves split at a dequeue", k.completed_solves, k.expected_solves, k.unsolved_items, k.wave_split);
+        if (k.completed_solves + k.cancelled_solves != k.expected_solves || k.unsolved_items != 0 || k.wave_split != 0) {
+            char buf[320];
+            snprintf(buf, sizeof buf, "methanation sweep incomplete: %llu of %llu DAE solves finished (+ %llu cancelled by the exact "
+                     "early rejection), %llu live items unsolved, %llu waves split at a dequeue", k.completed_solves,
+                     k.expected_solves, k.cancelled_solves, k.unsolved_items, k.wave_split);
             return fail(c, buf);
         }
     }

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/smc_hip.h"
+#include "sweep_args.h"   // RejectArgs, UserSolveArgs
 
 int smc_fail(smc_ctx *ctx, const char *msg);   // records the message (smc_last_error) and returns 1
 
@@ -51,19 +52,6 @@ struct ParticleSet {  // SoA view: theta[c][i] = theta_base[c*stride + i]
 };
 
 struct SweepCounters;
-
-// What the exact early-rejection bound of the solve kernel needs (mm_kernels.hip: mm_certainly_rejected).  Lives in DEVICE
-// memory (ctx->d_reject) and is written by the propose kernel of the sweep, so that the solve kernel carries one pointer
-// instead of nine kernel arguments in scalar registers through its attempt loops (144 SGPR spills).
-struct RejectArgs {
-    const double *lk1;          // likelihood of the current particles (lk1, Micmem_SMC_main.py:231)
-    const double *rr;           // host-RNG mode: the uniforms of :235
-    const double *pratio;       // prior_mode != MASK: p0_2 / p0_1
-    double gamma;
-    uint64_t seed, stream;
-    int64_t global_offset;
-    int device_rng, prior_mode;
-};
 
 // The list of predictably long solves ("stiff list") of a sweep: particles with Vmax > kStiffRatio * Km.  Built by the
 // propose kernel (Metropolis sweeps) or by mm_stiff_scan_kernel (likelihood sweeps), handed out by the solve kernel BEFORE
@@ -109,6 +97,7 @@ struct SweepCounters {  // device-side integer counters (order-independent atomi
     // unsolved (status still poisoned), waves that were incomplete at a dequeue.  A sweep is valid only if
     // completed == expected and the other two are zero (checked on the host after every sweep).
     unsigned long long expected_solves, completed_solves, unsolved_items, wave_split;
+    unsigned long long cancelled_solves;   // solves not started because their proposal was already certain to be rejected
 };
 
 struct EventPair {
@@ -178,6 +167,7 @@ struct smc_ctx {
     unsigned *d_stiff_count = nullptr;
     int stiff_parity = 0;
     int stiff_first = 1;                   // hand the predictably long solves out first (smc_set_stiff_first)
+    int exact_pow = 0;                     // parity mode: correctly rounded pow(x, -0.2) in the step controller (smc_set_exact_pow)
     bool solve_lds_raised = false;         // hipFuncAttributeMaxDynamicSharedMemorySize raised on THIS device
     int cu_count = 0, solve_blocks_per_cu = 0;
     // debug capture of the last MH iteration (lk2, accept flags; proposals live in SMC_SET_PRED)

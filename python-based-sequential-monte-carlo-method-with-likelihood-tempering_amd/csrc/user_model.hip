@@ -22,11 +22,19 @@
 
 #include "../../include/smc_hip.h"
 #include "smc_internal.h"
+#include "solve_sched.h"   // kChunk: the grid is sized in chunks of the shared scheduler
 
 namespace smc {
 
+// solve_sched.h, sweep_args.h and philox.h as strings (csrc/Makefile generates the file from the headers themselves): hiprtc
+// gets them as in-memory headers, so the run-time compiled kernel is scheduled by the very code the built-in kernel uses
+#include "embedded_headers.inc"
+
 static const char *kUserKernelSource = R"SRC(
 // ---- appended by libsmc_hip.so after the user's source -------------------------------------------------------
+#include "sweep_args.h"     // in-memory headers handed to hiprtc by the library: the argument blocks,
+#include "philox.h"         // the counter-based generator (the early-rejection bound re-derives the acceptance uniform),
+#include "solve_sched.h"    // and the scheduler the built-in Michaelis-Menten kernel uses
 #define NS SMC_USER_NS
 namespace smc_user {
 __device__ const double RK_A[6][5] = {
@@ -210,65 +218,165 @@ __device__ void item_attempt(Item &it, const double *theta, const double *cond, 
 }
 }  // namespace smc_user
 
-// Persistent lanes over the (experiment, particle) items: a lane that finishes its solve takes the next item from a
-// global counter, so the 100-fold spread of step counts over a prior-like population does not idle the wave
-// (the built-in Michaelis-Menten kernel schedules the same way).  item = e * n + p.
-// Outputs per item: the sum of squared residuals and attempts | failed << 30.
-extern "C" __global__ void __launch_bounds__(256)
-smc_user_solve_kernel(const double *theta_soa, long long stride, long long n, const unsigned char *p0mask, const double *t,
-                      const double *obs, const double *cond, int n_ex, int n_t, int n_cond, double rtol, double atol,
-                      double *sum_r2, int *info, unsigned long long *queue) {
-    const long long total = n * n_ex;
-    smc_user::Item it;
-    it.status = 1;
-    double th[SMC_USER_DIM];
-    bool live = false, exhausted = false;
-    long long item = 0;
-    int e = 0;
-    unsigned attempts = 0;
-    for (long long guard = 0; guard < (1LL << 40); ++guard) {
-        // refill in batches: setting up a solve (two right-hand sides, a pow) with one lane active costs the whole wave
-        // as much as an attempt, so idle lanes wait until 16 of them can start together (or nothing else is running)
-        const int n_idle = __popcll(__ballot(!live && !exhausted)), n_live = __popcll(__ballot(live));
-        const bool refill = n_idle >= 16 || n_live == 0;
-        while (refill && !live && !exhausted) {
-            item = (long long)atomicAdd(queue, 1ULL);
-            if (item >= total) {
-                exhausted = true;
-            } else {
-                const long long p = item % n;
-                e = (int)(item / n);
-                if (!(p0mask && p0mask[p] == 0)) {   // masked proposals are not solved
+// What solve_sched.h needs to know about an item of the user model (see the list at the top of that file): the built-in
+// Michaelis-Menten kernel's scheduler - chunked dequeue, pool of started items in LDS, tight attempt loop, uniform tail,
+// exact early rejection - runs the user's model unchanged (VERDICT r2 item 6).
+struct UserOps {
+    struct Item {
+        smc_user::Item s;
+        double th[SMC_USER_DIM];
+        long long out_idx;      // e * n + p
+        int e;
+        unsigned attempts;
+    };
+    static constexpr int kPoolWords = 2 * NS + 6;
+    const smc::UserSolveArgs &a;
+    long long n;
+    int n_ex;
+    const int *list;            // no list of predictably long items for a model the library knows nothing about
+    unsigned n_list;
+
+    __device__ __forceinline__ const double *cond(int e) const { return a.cond + (long long)e * a.n_cond; }
+    __device__ __forceinline__ const double *tt(int e) const { return a.t + (long long)e * a.n_t; }
+    __device__ __forceinline__ const double *ob(int e) const { return a.obs + (long long)e * a.n_t; }
+    __device__ __forceinline__ void publish(long long idx, double sum, int info) const {
+        // visible to the waves of other XCDs while the kernel runs (the early-rejection bound reads the siblings' sums)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.sum_r2) + idx, (unsigned long long)__double_as_longlong(sum),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.info[idx] = info;
+    }
+    __device__ __forceinline__ void load_theta(Item &it, long long p) const {
 #pragma unroll
-                    for (int c = 0; c < SMC_USER_DIM; ++c) th[c] = theta_soa[c * stride + p];
-                    smc_user::item_begin(it, th, cond + (long long)e * n_cond, t + (long long)e * n_t, obs + (long long)e * n_t,
-                                         n_t, rtol, atol);
-                    attempts = 0;
-                    live = true;
-                }
-            }
+        for (int c = 0; c < SMC_USER_DIM; ++c) it.th[c] = a.theta[c * a.stride + p];
+    }
+    __device__ __forceinline__ int start(long long p, int e, bool, Item &nb) const {
+        nb.out_idx = (long long)e * a.n + p;
+        nb.e = e;
+        nb.attempts = 0;
+        if (a.p0 && a.p0[p] == 0) {          // masked proposal: not solved, the accept kernel keeps lk1
+            publish(nb.out_idx, 0.0, 0);
+            return smc::kStartDone;
         }
-        if (!__any(live)) break;
-        if (live) {
-            if (it.status == 0) {
-                smc_user::item_attempt(it, th, cond + (long long)e * n_cond, t + (long long)e * n_t, obs + (long long)e * n_t, n_t,
-                                       rtol, atol);
-                ++attempts;
-                if (attempts >= 0x3fffffffu) it.status = -1;
-            }
-            if (it.status != 0) {
-                sum_r2[item] = it.sr2;
-                info[item] = (int)(attempts & 0x3fffffffu) | ((it.status < 0) ? (1 << 30) : 0);
-                live = false;
-            }
+        load_theta(nb, p);
+        smc_user::item_begin(nb.s, nb.th, cond(e), tt(e), ob(e), a.n_t, a.rtol, a.atol);
+        if (nb.s.status == 0) return smc::kStartStarted;
+        publish(nb.out_idx, nb.s.sr2, nb.s.status < 0 ? (1 << 30) : 0);
+        return smc::kStartDone;
+    }
+    __device__ __forceinline__ void pack(const Item &nb, double *slot) const {
+        slot[0 * 64] = nb.s.t;
+        slot[1 * 64] = nb.s.h_abs;
+        slot[2 * 64] = nb.s.sr2;
+        slot[3 * 64] = __hiloint2double(nb.s.i_out, (int)nb.s.rejected);
+        slot[4 * 64] = __hiloint2double((int)nb.attempts, nb.e);
+        slot[5 * 64] = __longlong_as_double(nb.out_idx);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            slot[(6 + i) * 64] = nb.s.y[i];
+            slot[(6 + NS + i) * 64] = nb.s.f[i];
         }
     }
+    __device__ __forceinline__ void unpack(Item &it, const double *slot) const {
+        it.s.t = slot[0 * 64];
+        it.s.h_abs = slot[1 * 64];
+        it.s.sr2 = slot[2 * 64];
+        const double w3 = slot[3 * 64], w4 = slot[4 * 64];
+        it.s.rejected = __double2loint(w3) != 0;
+        it.s.i_out = __double2hiint(w3);
+        it.e = __double2loint(w4);
+        it.attempts = (unsigned)__double2hiint(w4);
+        it.out_idx = __double_as_longlong(slot[5 * 64]);
+        it.s.status = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            it.s.y[i] = slot[(6 + i) * 64];
+            it.s.f[i] = slot[(6 + NS + i) * 64];
+        }
+        load_theta(it, it.out_idx - (long long)it.e * a.n);      // the parameters come from HBM / L2 again, not through the pool
+    }
+    __device__ __forceinline__ int attempt(Item &it) const {
+        smc_user::item_attempt(it.s, it.th, cond(it.e), tt(it.e), ob(it.e), a.n_t, a.rtol, a.atol);
+        ++it.attempts;
+        if (it.attempts >= 0x1fffffffu) it.s.status = -1;        // hard bound so that every wave drains
+        return it.s.status;
+    }
+    __device__ __forceinline__ void finish(Item &it, int st) const {
+        publish(it.out_idx, it.s.sr2, (int)(it.attempts & 0x1fffffffu) | ((st < 0) ? (1 << 30) : 0));
+    }
+    __device__ __forceinline__ Item broadcast(const Item &it, int src) const {
+        Item u;
+        u.s.t = smc::lane_value(it.s.t, src);
+        u.s.h_abs = smc::lane_value(it.s.h_abs, src);
+        u.s.sr2 = smc::lane_value(it.s.sr2, src);
+        u.s.i_out = __builtin_amdgcn_readlane(it.s.i_out, src);
+        u.s.status = __builtin_amdgcn_readlane(it.s.status, src);
+        u.s.rejected = __builtin_amdgcn_readlane((int)it.s.rejected, src) != 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            u.s.y[i] = smc::lane_value(it.s.y[i], src);
+            u.s.f[i] = smc::lane_value(it.s.f[i], src);
+        }
+#pragma unroll
+        for (int c = 0; c < SMC_USER_DIM; ++c) u.th[c] = smc::lane_value(it.th[c], src);
+        u.out_idx = smc::lane_value_ll(it.out_idx, src);
+        u.e = __builtin_amdgcn_readlane(it.e, src);
+        u.attempts = (unsigned)__builtin_amdgcn_readlane((int)it.attempts, src);
+        return u;
+    }
+    __device__ __forceinline__ bool reject_enabled() const { return a.rej != nullptr; }
+    // EXACT early rejection, as for the built-in model (mm_kernels.hip: mm_certainly_rejected): the Gaussian likelihood
+    // lk2 = sum_e [c0 - sum_r2_e / (2 sigma^2)] (Micmem_likelihood.py:70-73) only falls while a solve accumulates squared
+    // residuals, lk1 and rr are fixed before the sweep, so a proposal that fails exp((lk2 - lk1) gamma) >= rr with the sums
+    // accumulated SO FAR (0 for a sibling still running) is rejected whatever the rest would add.  The expression is the
+    // one user_finish_kernel evaluates, in the same order.
+    __device__ __forceinline__ bool certainly_rejected(const Item &it) const {
+        const long long p = it.out_idx - (long long)it.e * a.n;
+        const double sigma = a.est_sigma ? it.th[SMC_USER_DIM - 1] : a.sigma_fixed;
+        if (!(sigma > 0.0)) return false;
+        const double s2 = sigma * sigma;
+        const double c0 = (-0.5 * a.n_t) * log(2.0 * 3.141592653589793 * s2);
+        double lk2_bound = 0.0;
+        for (int k = 0; k < a.n_ex; ++k) {
+            double S = 0.0;
+            if (k == it.e) {
+                S = it.s.sr2;
+            } else {
+                const double v = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<unsigned long long *>(a.sum_r2) + (long long)k * a.n + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (v < 0.0) return true;      // a sibling has already established the rejection
+                if (v == v) S = v;             // finished; NaN = still running: counts as 0
+            }
+            lk2_bound += c0 - S / (2.0 * s2);
+        }
+        const smc::RejectArgs &r = *a.rej;
+        double rr;
+        if (r.device_rng) {
+            const smc::u32x4 ru = smc::philox_block(r.seed, (unsigned long long)(r.global_offset + p), r.stream, SMC_PHILOX_BLOCK_UNIFORM);
+            rr = smc::u01_from(ru.x, ru.y);
+        } else {
+            rr = r.rr[p];
+        }
+        double pp = exp((lk2_bound - r.lk1[p]) * r.gamma);
+        if (r.prior_mode != 0) pp = pp * r.pratio[p];      // SMC_PRIOR_MODE_MASK == 0
+        return pp < rr * (1.0 - 1e-12);
+    }
+    __device__ __forceinline__ void cancel(Item &it) const {
+        publish(it.out_idx, -1.0, (int)(it.attempts & 0x1fffffffu) | (1 << 29));
+    }
+};
+
+// Outputs per item: the sum of squared residuals and attempts | cancelled << 29 | failed << 30.
+extern "C" __global__ void __launch_bounds__(256) smc_user_solve_kernel(smc::UserSolveArgs a) {
+    extern __shared__ double s_pool_all[];       // per wave: a ring of 64 started items of UserOps::kPoolWords words
+    double *s_pool = s_pool_all + (threadIdx.x >> 6) * (UserOps::kPoolWords * 64);
+    UserOps ops{a, a.n, a.n_ex, nullptr, 0u};
+    smc::solve_persistent(ops, a.queue, s_pool);
 }
 )SRC";
 
 // log-likelihood of Micmem_likelihood.py:62-73 per particle from the per-item sums; counters as in the built-in path
 __global__ void __launch_bounds__(256)
-user_finish_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, int dim, const uint8_t *__restrict__ p0mask,
+user_finish_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, int dim, uint8_t *__restrict__ p0mask,
                    const double *__restrict__ sum_r2, const int *__restrict__ info, int n_ex, int n_t, int est_sigma,
                    double sigma_fixed, double *__restrict__ lk_out, SweepCounters *__restrict__ counters) {
     unsigned long long attempts = 0, failed = 0;
@@ -280,14 +388,19 @@ user_finish_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, 
             const double s2 = sigma * sigma;
             const double c0 = (-0.5 * n_t) * log(2.0 * 3.141592653589793 * s2);
             double lk = 0.0;
-            unsigned pf = 0;
+            unsigned pf = 0, cancelled = 0;
             for (int e = 0; e < n_ex; ++e) {
                 lk += c0 - sum_r2[(int64_t)e * n + p] / (2.0 * s2);
                 const int fl = info[(int64_t)e * n + p];
-                attempts += (unsigned)(fl & 0x3fffffff);
+                attempts += (unsigned)(fl & 0x1fffffff);
                 pf |= (unsigned)(fl >> 30) & 1u;
+                cancelled |= (unsigned)(fl >> 29) & 1u;
             }
             failed += pf;
+            if (cancelled) {      // a solve stopped because the rejection was certain: logL was never completed - the accept
+                lk = __longlong_as_double(0x7ff8000000000000LL);   // kernel sees the flag and keeps p_filt, lk1
+                if (p0mask) p0mask[p] = 2;
+            }
             lk_out[p] = lk;
         }
     }
@@ -301,6 +414,7 @@ struct UserModel {
     double *d_t = nullptr, *d_obs = nullptr, *d_cond = nullptr, *d_sum = nullptr;
     int *d_info = nullptr;
     int n_ex = 0, n_t = 0, n_cond = 0, n_states = 0, est_sigma = 1;
+    int blocks_per_cu = 4;   // persistent blocks (4 waves each) per CU: what the compiled kernel's registers and LDS allow
     double sigma_fixed = 0, rtol = 1e-3, atol = 1e-6;
 };
 
@@ -313,7 +427,9 @@ static std::string build_source(const char *user_source, int n_states, int dim) 
 // compile for gfx950; on failure `log` holds hiprtc's diagnostics
 static bool compile_user(const std::string &src, std::vector<char> &code, std::string &log) {
     hiprtcProgram prog;
-    if (hiprtcCreateProgram(&prog, src.c_str(), "smc_user_model.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    const char *headers[] = {k_sweep_args_h, k_philox_h, k_solve_sched_h};
+    const char *names[] = {"sweep_args.h", "philox.h", "solve_sched.h"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "smc_user_model.hip", 3, headers, names) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
         return false;
     }
@@ -350,19 +466,40 @@ void user_model_release(smc_ctx *c) {
     c->user = nullptr;
 }
 
-static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask, double *lk) {
+static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, int64_t n, uint8_t *p0mask, double *lk,
+                               bool reject) {
     UserModel *u = (UserModel *)c->user;
-    long long stride_ = stride, n_ = n;
-    const int64_t total = n * u->n_ex;
-    int64_t blocks = (total + 255) / 256;
-    const int64_t cap = (int64_t)c->cu_count * 8;
-    if (blocks > cap) blocks = cap;
-    void *args[] = {(void *)&theta, &stride_, &n_, (void *)&p0mask, &u->d_t, &u->d_obs, &u->d_cond, &u->n_ex, &u->n_t,
-                    &u->n_cond, &u->rtol, &u->atol, &u->d_sum, &u->d_info, &c->d_queue};
+    UserSolveArgs a{};
+    a.theta = theta;
+    a.stride = stride;
+    a.n = n;
+    a.p0 = p0mask;
+    a.t = u->d_t;
+    a.obs = u->d_obs;
+    a.cond = u->d_cond;
+    a.n_ex = u->n_ex;
+    a.n_t = u->n_t;
+    a.n_cond = u->n_cond;
+    a.dim = c->dim;
+    a.est_sigma = u->est_sigma;
+    a.sigma_fixed = u->sigma_fixed;
+    a.rtol = u->rtol;
+    a.atol = u->atol;
+    a.sum_r2 = u->d_sum;
+    a.info = u->d_info;
+    a.queue = c->d_queue;
+    a.rej = reject ? c->d_reject : nullptr;
+    // persistent grid: the waves take chunks of kChunk items until the queue is empty (solve_sched.h)
+    const int64_t chunks = (((n + 63) / 64) * 64 * u->n_ex + kChunk - 1) / kChunk;
+    int64_t blocks = (int64_t)c->cu_count * u->blocks_per_cu;
+    if (blocks > (chunks + 3) / 4) blocks = (chunks + 3) / 4;
+    if (blocks < 1) blocks = 1;
+    const unsigned lds = (unsigned)(4 * (2 * u->n_states + 6) * 64 * sizeof(double));   // four waves' pools of started items
+    void *args[] = {&a};
     {
         ScopedTimer tm(c, SMC_T_SOLVE);
         (void)hipMemsetAsync(c->d_queue, 0, sizeof(unsigned long long), c->stream);
-        const hipError_t e = hipModuleLaunchKernel(u->fn, (unsigned)blocks, 1, 1, 256, 1, 1, 0, c->stream, args, nullptr);
+        const hipError_t e = hipModuleLaunchKernel(u->fn, (unsigned)blocks, 1, 1, 256, 1, 1, lds, c->stream, args, nullptr);
         if (e != hipSuccess) {
             smc_fail(c, (std::string("launch of the user-model kernel failed: ") + hipGetErrorString(e)).c_str());
             c->launch_failed = true;
@@ -375,14 +512,24 @@ static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, 
 }
 
 void launch_user_loglik(smc_ctx *c, const double *theta, int64_t stride, int64_t n, double *lk) {
-    if (n > 0) launch_user_kernel(c, theta, stride, n, nullptr, lk);
+    if (n > 0) launch_user_kernel(c, theta, stride, n, nullptr, lk, false);
 }
 
-void launch_user_mh(smc_ctx *c, int64_t n, const MHParams &mh) {
+void launch_user_mh(smc_ctx *c, int64_t n, const MHParams &mh_in) {
     if (n <= 0) return;
     ParticleSet &P = c->set[SMC_SET_PRED];
+    UserModel *u = (UserModel *)c->user;
+    // exact early rejection (UserOps::certainly_rejected): off while the proposals' likelihoods are captured for inspection
+    const bool reject = c->early_reject != 0 && c->debug_capture == 0 && mh_in.gamma > 0.0 && c->d_reject;
+    MHParams mh = mh_in;
+    if (reject) {
+        mh.pending_sums = u->d_sum;          // the propose kernel marks every item of the sweep "not finished yet"
+        mh.pending_n_ex = u->n_ex;
+        mh.reject_out = c->d_reject;
+        mh.reject_lk1 = c->set[SMC_SET_FILT].lk;
+    }
     launch_generic_propose(c, n, mh);
-    launch_user_kernel(c, P.theta, P.stride, n, c->d_p0, c->d_mlk2);
+    launch_user_kernel(c, P.theta, P.stride, n, c->d_p0, c->d_mlk2, reject);
     launch_generic_accept(c, n, mh, c->d_mlk2);
 }
 
@@ -438,6 +585,16 @@ int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const doubl
     if (!ok) {
         user_model_release(c);
         return smc_fail(c, "smc_set_model_user: device allocation / upload failed");
+    }
+    {   // occupancy of the compiled kernel with its pool in LDS
+        int nb = 0;
+        const size_t lds = (size_t)4 * (2 * n_states + 6) * 64 * sizeof(double);
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, u->fn, 256, lds) == hipSuccess && nb >= 1) u->blocks_per_cu = nb;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(u->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            user_model_release(c);
+            return smc_fail(c, "smc_set_model_user: raising the dynamic LDS limit of the compiled kernel failed");
+        }
     }
     u->n_ex = n_ex;
     u->n_t = n_t;

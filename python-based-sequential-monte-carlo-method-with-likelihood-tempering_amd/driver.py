@@ -322,6 +322,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         engine.set_early_reject(s.early_reject)
     if hasattr(engine, "set_stiff_first"):
         engine.set_stiff_first(s.stiff_first)
+    if hasattr(engine, "set_exact_pow"):           # parity mode (the reference's NumPy stream): libm-grade step-controller power
+        engine.set_exact_pow(rng == "numpy")
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "ess_syncs": 0, "ess_search_s": 0.0, "particle_mutation_steps": 0}
@@ -334,6 +336,9 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         if meth:                                   # K8 work counters of the sweep just done
             for k, v in engine.meth_sweep_counters().items():
                 stats[k] = stats.get(k, 0) + v
+            chk = engine.meth_sweep_check()        # solves done / skipped by the exact early rejection
+            stats["dae_solves"] = stats.get("dae_solves", 0) + chk["completed_solves"]
+            stats["dae_solves_cancelled"] = stats.get("dae_solves_cancelled", 0) + chk.get("cancelled_solves", 0)
 
     gamma_old, gamma_new = 0.0, 1.0
     logZ = 0.0

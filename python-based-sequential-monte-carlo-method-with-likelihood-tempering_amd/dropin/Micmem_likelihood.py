@@ -31,6 +31,8 @@ def _engine(n):
         P = np.stack([np.asarray(d["P_obs"], dtype=np.float64) for d in dataset])      # noqa: F405
         S0 = np.array([float(d["S0"]) for d in dataset])                               # noqa: F405
         _ENGINE.set_model_mm(t, P, S0, est_sigma=est_sigma, sigma_fixed=sigma_true)    # noqa: F405
+        if hasattr(_ENGINE, "set_exact_pow"):
+            _ENGINE.set_exact_pow(True)     # the reference's drivers run on NumPy's stream: libm-grade step-controller power
     return _ENGINE
 
 
@@ -65,6 +67,7 @@ def simulate_mm_on_grid(Vmax, Km, S0, t_array):
     t_array = np.ascontiguousarray(t_array, dtype=np.float64)
     with _HipEngine(1, 3, device=0) as eng:
         eng.set_model_mm(t_array[None, :], np.zeros((1, len(t_array))), np.array([float(S0)]))
+        eng.set_exact_pow(True)
         _, pred, info = eng.loglik_host(np.array([[Vmax, Km, 1.0]]), want_pred=True)
     if info["n_failed"]:
         raise RuntimeError("RK45 did not reach t_bound (SciPy: status -1)")

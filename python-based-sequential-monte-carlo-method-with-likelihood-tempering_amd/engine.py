@@ -153,9 +153,10 @@ class HipEngine:
 
     def meth_sweep_check(self):
         """Completeness of the last methanation sweep (the library already fails the sweep when these disagree)."""
-        out = (ctypes.c_int64 * 4)()
+        out = (ctypes.c_int64 * 5)()
         self._ck(self.L.smc_meth_sweep_check(self.ctx, out), "smc_meth_sweep_check")
-        return {"expected_solves": out[0], "completed_solves": out[1], "unsolved_items": out[2], "wave_split": out[3]}
+        return {"expected_solves": out[0], "completed_solves": out[1], "unsolved_items": out[2], "wave_split": out[3],
+                "cancelled_solves": out[4]}
 
     def meth_download_solves(self, n=None):
         """Outlet flows (n, n_data, 5) and solver status (n, n_data) of the last methanation sweep."""
@@ -174,8 +175,15 @@ class HipEngine:
         self._ck(self.L.smc_set_prior_mode(self.ctx, m), "smc_set_prior_mode")
 
     def set_early_reject(self, enable=True):
-        """Stop a Michaelis-Menten solve once its proposal is certainly rejected (include/smc_hip.h: smc_set_early_reject)."""
+        """Stop (Michaelis-Menten) or do not start (methanation) the solves of a proposal that is already certain to be rejected
+        (include/smc_hip.h: smc_set_early_reject, smc_meth_sweep_check)."""
         self._ck(self.L.smc_set_early_reject(self.ctx, int(bool(enable))), "smc_set_early_reject")
+
+    def set_exact_pow(self, enable=True):
+        """Parity mode of the step controller: correctly rounded pow(x, -0.2) (include/smc_hip.h: smc_set_exact_pow)."""
+        if "smc_set_exact_pow" in B.MISSING:       # A/B build of an older revision (SMC_HIP_LIB)
+            return
+        self._ck(self.L.smc_set_exact_pow(self.ctx, int(bool(enable))), "smc_set_exact_pow")
 
     def set_stiff_first(self, enable=True):
         """Hand the predictably long Michaelis-Menten solves out first (include/smc_hip.h: smc_set_stiff_first)."""

@@ -57,11 +57,16 @@ def test_largest_data_set_vs_checker(pkg, O):
 @pytest.mark.gpu
 def test_stiff_band_parity_and_its_tolerance(pkg, O):
     """Km log-uniform over 1e-3 .. 10: a quarter of the particles sit in the band where RK45 runs on its stability limit
-    (thousands of attempts per solve).  The device's inverse fifth root (<= 1.5 ulp) is not libm's pow: a last-bit
-    difference in one step size can flip one accept / reject decision of the step controller, after which the two
-    integrations follow different, equally valid step sequences and logL differs at 1e-8 .. 1e-6 instead of 1e-12 - far
-    inside the rtol = 1e-3 of the solve itself.  Stated tolerance: every particle within 1e-6, at most 0.2 % of them beyond
-    1e-9, attempt totals within 1e-5 (a randomised soak over 160 shapes and sizes gave 2.8e-7 at worst)."""
+    (thousands of attempts per solve).
+    * Default (fast) mode: the device's inverse fifth root (<= 1.5 ulp about x^(-1/5)) is not libm's pow(x, -0.2) - whose
+      DOUBLE exponent is -(1/5 + 1.1e-17), more than an ulp away from the fifth root for small error norms: a last-bit
+      difference in one step size can flip one accept / reject decision of the step controller, after which the two
+      integrations follow different, equally valid step sequences and logL differs at 1e-8 .. 1e-6 instead of 1e-12 - far
+      inside the rtol = 1e-3 of the solve itself.  Stated tolerance: every particle within 1e-6, at most 0.2 % of them
+      beyond 1e-9, attempt totals within 1e-5 (a randomised soak over 160 shapes and sizes gave 2.8e-7 at worst).
+    * Parity mode (smc_set_exact_pow, what run_smc(rng="numpy") and the drop-in sim_particle use): the power is finished to
+      the correctly rounded pow(x, -0.2) - libm's value except for ~8 of 10^4 arguments where glibc itself is not
+      correctly rounded (tests/test_pow_fifth_exact.py).  EVERY particle within 1e-9 and the attempt totals EQUAL."""
     rs = np.random.RandomState(2024)
     n = 20000
     t = np.tile(np.linspace(0, 10, 40), (6, 1))
@@ -72,10 +77,18 @@ def test_stiff_band_parity_and_its_tolerance(pkg, O):
     with pkg.HipEngine(n, 3, device=0) as eng:
         eng.set_model_mm(t, P_obs, S0)
         lk, _, info = eng.loglik_host(th)
+        eng.set_exact_pow(True)
+        lk_x, _, info_x = eng.loglik_host(th)
     err = np.abs(lk - ref) / np.maximum(1.0, np.abs(ref))
     assert info["n_failed"] == 0 and err.max() < 1e-6, err.max()
     assert (err > 1e-9).sum() <= 2e-3 * n, int((err > 1e-9).sum())
     assert abs(info["rk_attempts"] - iref["n_attempts"]) <= 1e-5 * iref["n_attempts"]
+    err_x = np.abs(lk_x - ref) / np.maximum(1.0, np.abs(ref))
+    print(f"stiff band, {n} particles: fast mode max err {err.max():.2e}, {int((err > 1e-9).sum())} beyond 1e-9, attempts "
+          f"{info['rk_attempts']} vs {iref['n_attempts']}; parity mode max err {err_x.max():.2e}, "
+          f"{int((err_x > 1e-9).sum())} beyond 1e-9, attempts {info_x['rk_attempts']}")
+    assert info_x["n_failed"] == 0 and err_x.max() < 1e-9, (err_x.max(), int((err_x > 1e-9).sum()))
+    assert info_x["rk_attempts"] == iref["n_attempts"]
 
 
 @pytest.mark.gpu

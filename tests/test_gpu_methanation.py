@@ -288,7 +288,8 @@ def test_config4_full_size_sweeps_complete(pkg, M, cond_guess):
         assert np.all(theta >= lo[pos]) and np.all(theta <= hi[pos])
         info = eng.loglik(pkg.SMC_SET_PRED)                                  # 3e6 solves
         chk = eng.meth_sweep_check()
-        assert chk == {"expected_solves": n * 30, "completed_solves": n * 30, "unsolved_items": 0, "wave_split": 0}, chk
+        assert chk == {"expected_solves": n * 30, "completed_solves": n * 30, "unsolved_items": 0, "wave_split": 0,
+                       "cancelled_solves": 0}, chk
         k8 = eng.meth_sweep_counters()
         flows, status = eng.meth_download_solves()
         assert set(np.unique(status).tolist()) <= {0, 1}
@@ -340,7 +341,7 @@ def test_config4_full_size_sweeps_complete(pkg, M, cond_guess):
         n_live = int(p0_ref.sum())
         chk = eng.meth_sweep_check()
         assert chk == {"expected_solves": n_live * 30, "completed_solves": n_live * 30, "unsolved_items": 0,
-                       "wave_split": 0}, chk
+                       "wave_split": 0, "cancelled_solves": 0}, chk      # debug capture switches early rejection off
         _, status2 = eng.meth_download_solves()
         assert np.all(status2[~p0_ref] == -1) and np.all(status2[p0_ref] >= 0)   # masked proposals were not solved
         f = eng.download_particles(pkg.SMC_SET_FILT)
@@ -351,3 +352,82 @@ def test_config4_full_size_sweeps_complete(pkg, M, cond_guess):
         assert np.array_equal(r.astype(bool), r_ref) and out["accepted_now"] == int(r_ref.sum())
         assert np.array_equal(f[r_ref], prop[r_ref]) and np.array_equal(f[~r_ref], theta[~r_ref])
         assert np.array_equal(lk1[r_ref], lk2[r_ref]) and np.array_equal(lk1[~r_ref], lk[~r_ref])
+        flags_off = eng.download_accept_flags()
+
+        # the SAME Metropolis iteration with exact early rejection (VERDICT r2 item 3, config 4's size): nothing observable
+        # may change, every item is either solved or cancelled, and a good share of the 2e6 solves is not started
+        eng.set_debug_capture(False)
+        eng.set_early_reject(True)
+        eng.upload_particles(pkg.SMC_SET_FILT, theta)
+        eng.upload_lk(pkg.SMC_SET_FILT, lk)
+        eng.reset_accept_flags()
+        out_on = eng.mh_step_host_rng(gamma, 1.0, noise, rr)
+        chk_on = eng.meth_sweep_check()
+        assert chk_on["expected_solves"] == n_live * 30 == chk_on["completed_solves"] + chk_on["cancelled_solves"]
+        assert chk_on["unsolved_items"] == 0 and chk_on["wave_split"] == 0
+        assert chk_on["cancelled_solves"] > 0.01 * n_live * 30, chk_on      # small steps (1 % of the box), gamma = 0.01: 3 %
+        print(f"config 4 Metropolis sweep with early rejection: {chk_on['cancelled_solves']} of {n_live * 30} solves not started "
+              f"({100.0 * chk_on['cancelled_solves'] / (n_live * 30):.1f} %)")
+        assert out_on["accepted_now"] == out["accepted_now"] and out_on["accepted_ever"] == out["accepted_ever"]
+        assert np.array_equal(eng.download_particles(pkg.SMC_SET_FILT), f)
+        assert np.array_equal(eng.download_lk(pkg.SMC_SET_FILT), lk1)
+        assert np.array_equal(eng.download_accept_flags(), flags_off)
+        _, status3 = eng.meth_download_solves()
+        cancelled_particles = (status3 == -2).any(axis=1)
+        assert not r_ref[cancelled_particles].any()                             # only rejected proposals lose solves
+        assert np.all(status3[~p0_ref] == -1) and np.all(status3[p0_ref] != -1)
+
+
+def test_methanation_early_rejection_changes_nothing_but_the_solve_count(pkg, M, cond_guess):
+    """Exact early rejection at N = 192: one host-RNG Metropolis iteration on a prior-drawn population
+    at three tempering exponents, and a complete device-RNG run, each with the feature on and off: selected particles,
+    likelihoods, accept flags and counts, the tempering schedule and the evidence are bit-identical; the number of DAE
+    solves is smaller and completed + cancelled == asked for in every sweep (the library checks that itself and fails the
+    sweep otherwise: smc_meth_sweep_check)."""
+    cond, guess = cond_guess
+    np.random.seed(20250205)
+    flows0, _, _ = M.my_model(M.BASEPARAMS, cond, guess)
+    obs = flows0 + 5.0 * np.random.standard_normal(flows0.shape)
+    n = 192
+    lo, hi, pos = M.prior_box()
+    rs = np.random.RandomState(8)
+    theta = lo[pos] + (hi[pos] - lo[pos]) * rs.uniform(0, 1, (n, 5))
+    noise = rs.standard_normal((n, 5)) * (hi[pos] - lo[pos]) * 0.05
+    rr = rs.uniform(0, 1, n)
+    eng, s = _meth_engine(pkg, M, cond, guess, obs, n)
+    with eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, theta)
+        eng.loglik(pkg.SMC_SET_PRED)
+        lk = eng.download_lk(pkg.SMC_SET_PRED)
+        for gamma in (1e-4, 1e-2, 1.0):
+            res = {}
+            for on in (False, True):
+                eng.set_early_reject(on)
+                eng.upload_particles(pkg.SMC_SET_FILT, theta)
+                eng.upload_lk(pkg.SMC_SET_FILT, lk)
+                eng.reset_accept_flags()
+                out = eng.mh_step_host_rng(gamma, 1.0, noise, rr)
+                chk = eng.meth_sweep_check()
+                assert chk["completed_solves"] + chk["cancelled_solves"] == chk["expected_solves"] and chk["unsolved_items"] == 0
+                res[on] = (out["accepted_now"], out["accepted_ever"], eng.download_particles(pkg.SMC_SET_FILT),
+                           eng.download_lk(pkg.SMC_SET_FILT), eng.download_accept_flags(), chk)
+            a, b = res[True], res[False]
+            assert a[0] == b[0] and a[1] == b[1]
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+            assert b[5]["cancelled_solves"] == 0 and a[5]["expected_solves"] == b[5]["expected_solves"]
+            print(f"gamma {gamma}: {a[5]['cancelled_solves']} of {a[5]['expected_solves']} solves cancelled, {a[0]} accepted")
+            if gamma >= 1e-2:
+                assert a[5]["cancelled_solves"] > 0
+    runs = {}
+    for on in (True, False):
+        eng, s = _meth_engine(pkg, M, cond, guess, obs, n)
+        s.early_reject = on
+        with eng:
+            runs[on] = pkg.run_smc(eng, s, rng="device", verbose=False, seed_device=5)
+    a, b = runs[True], runs[False]
+    assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
+    assert [r_["n_accept"] for r_ in a["records"]] == [r_["n_accept"] for r_ in b["records"]]
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+    assert b["stats"]["dae_solves_cancelled"] == 0 < a["stats"]["dae_solves_cancelled"]
+    assert a["stats"]["dae_solves"] + a["stats"]["dae_solves_cancelled"] == b["stats"]["dae_solves"]
+    print(f"full run, N = 192: {a['stats']['dae_solves']} solves with early rejection, {b['stats']['dae_solves']} without")

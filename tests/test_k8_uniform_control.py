@@ -101,7 +101,7 @@ def test_mm_solve_kernel_has_no_cross_lane_operation_in_a_loop_that_lanes_leave_
     divergent and compiled the 'uniform' attempt loop with exec-mask control flow (tools/uniformity_report.py)."""
     U = _load_tool("uniformity_report")
     ll, uni = U.compile_ir(os.path.join(CSRC, "mm_kernels.hip"), str(tmp_path))
-    for inst in ("mm_solve_kernelILb0", "mm_solve_kernelILb1"):
+    for inst in ("mm_solve_kernelILb0ELb0", "mm_solve_kernelILb0ELb1", "mm_solve_kernelILb1ELb0", "mm_solve_kernelILb1ELb1"):
         name, cycles, n_div = U.kernel_cycles(ll, uni, inst)
         assert n_div > 0                                   # the per-lane branches are there: the parser saw the kernel
         bad = [(c["depth"], len(c["blocks"]), c["cross_lane"][:3]) for c in cycles if c["cross_lane"]]
@@ -122,7 +122,7 @@ def test_mm_chunk_dequeue_in_the_isa(tmp_path):
     subprocess.run([HIPCC, *FLAGS, "-DSMC_ISA_MARKS", "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, "mm_kernels.hip")],
                    check=True, stderr=subprocess.DEVNULL, timeout=600)
     lines = open(asm).read().split("\n")
-    for inst in ("mm_solve_kernelILb0", "mm_solve_kernelILb1"):
+    for inst in ("mm_solve_kernelILb0ELb0", "mm_solve_kernelILb0ELb1", "mm_solve_kernelILb1ELb0", "mm_solve_kernelILb1ELb1"):
         start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3smc15" + inst + r"\w*:", l))
         end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
         body = [l.strip() for l in lines[start:end]]
