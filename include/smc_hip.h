@@ -154,9 +154,12 @@ int smc_set_stiff_first(smc_ctx *ctx, int enable);
  * bit of many arguments; on RK45's stability limit one such bit can flip one accept / reject decision and the solve then
  * follows another, equally valid step sequence (logL equal to 1e-8 ... 1e-6 only).  enable != 0 finishes the fast value to
  * the CORRECTLY ROUNDED pow(x, -0.2) / pow(x, 0.2) (double-double residual, csrc/pow_fifth_exact.h; checked against a 113-bit
- * reference on the CPU) at ~15 more operations per attempt: what libm returns except for about 8 of 10^4 arguments where
- * glibc's own pow is not correctly rounded.  run_smc switches it on with rng="numpy" (the reference's stream) and the
- * drop-in sim_particle uses it; the device-RNG default keeps the fast form. */
+ * reference on the CPU) - what libm returns except for about 8 of 10^4 arguments where glibc's own pow is not correctly
+ * rounded - AND evaluates the Runge-Kutta stages, the error estimate and select_initial_step with every product and sum
+ * rounded separately, in NumPy's order (no fused multiply-add; mm_rk45.h: rk_attempt_core_exact), as the CPU checker does:
+ * the device then walks the checker's step sequence attempt for attempt, also in the stiff band
+ * (test_stiff_band_parity_and_its_tolerance).  About 60 more operations per attempt.  run_smc switches it on with
+ * rng="numpy" (the reference's stream) and the drop-in sim_particle uses it; the device-RNG default keeps the fast form. */
 int smc_set_exact_pow(smc_ctx *ctx, int enable);
 int smc_set_resampling(smc_ctx *ctx, int scheme);
 

@@ -34,7 +34,8 @@ static const char *kUserKernelSource = R"SRC(
 // ---- appended by libsmc_hip.so after the user's source -------------------------------------------------------
 #include "sweep_args.h"     // in-memory headers handed to hiprtc by the library: the argument blocks,
 #include "philox.h"         // the counter-based generator (the early-rejection bound re-derives the acceptance uniform),
-#include "solve_sched.h"    // and the scheduler the built-in Michaelis-Menten kernel uses
+#include "solve_sched.h"    // the scheduler the built-in Michaelis-Menten kernel uses,
+#include "rk45_math.h"      // and its step-controller arithmetic (fast inverse fifth root, min_step)
 #define NS SMC_USER_NS
 namespace smc_user {
 __device__ const double RK_A[6][5] = {
@@ -60,6 +61,7 @@ __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? 
 __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
 // common.py:63-65  np.linalg.norm(x) / x.size ** 0.5
 __device__ __forceinline__ double rms(const double *x) {
+    if (NS == 1) return fabs(x[0]);   // sqrt(x*x) / sqrt(1) is |x| exactly in IEEE arithmetic (as the built-in kernel writes it)
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) s += x[i] * x[i];
@@ -113,7 +115,8 @@ __device__ void item_begin(Item &it, const double *theta, const double *cond, co
 #pragma unroll
         for (int i = 0; i < NS; ++i) tmp[i] = (f1[i] - it.f[i]) / scale[i];
         const double d2 = rms(tmp) / h0;
-        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? py_max(1e-6, h0 * 1e-3) : pow(0.01 / py_max(d1, d2), 1.0 / 5);
+        // x ** (1 / 5) as the built-in kernel evaluates it: the reciprocal of the fast inverse fifth root (rk45_math.h)
+        const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? py_max(1e-6, h0 * 1e-3) : 1.0 / smc::pow_minus_fifth<false>(0.01 / py_max(d1, d2));
         it.h_abs = py_min(py_min(py_min(100 * h0, h1), interval_length), inf);
     }
     if (it.t == t_bound) {   // base.py:181-187: nothing to integrate
@@ -127,7 +130,7 @@ __device__ void item_attempt(Item &it, const double *theta, const double *cond, 
     const double t_bound = t_eval[n_t - 1];
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     const double t = it.t;
-    const double min_step = 10 * fabs(nextafter(t, inf) - t);
+    const double min_step = (t >= 0.0) ? smc::min_step_of(t) : 10 * fabs(nextafter(t, inf) - t);
     // rk.py:111-121: clip at the start of a step (a value raised here stays raised for the re-tries of the step)
     if (!it.rejected && it.h_abs < min_step) it.h_abs = min_step;
     if (it.h_abs < min_step) { it.status = -1; return; }
@@ -170,12 +173,15 @@ __device__ void item_attempt(Item &it, const double *theta, const double *cond, 
         tmp[i] = acc * h / scale;
     }
     const double error_norm = rms(tmp);
+    // error_norm ** -0.2 (rk.py:155,169) by the dedicated inverse fifth root of the built-in kernel (<= 1.5 ulp; the generic
+    // pow costs 350 ns on the dependent chain of an attempt): 0 -> inf, which min(10, .) turns into MAX_FACTOR
+    const double pw = 0.9 * smc::pow_minus_fifth<false>(error_norm);
     if (!(error_norm < 1)) {   // rejected (also for a NaN norm: Python's max(0.2, nan) is 0.2)
-        it.h_abs *= py_max(0.2, 0.9 * pow(error_norm, -0.2));
+        it.h_abs *= py_max(0.2, pw);
         it.rejected = true;
         return;
     }
-    double factor = (error_norm == 0) ? 10.0 : py_min(10.0, 0.9 * pow(error_norm, -0.2));
+    double factor = py_min(10.0, pw);
     if (it.rejected) factor = py_min(1.0, factor);
     it.h_abs *= factor;
     it.rejected = false;
@@ -237,8 +243,9 @@ struct UserOps {
     unsigned n_list;
 
     __device__ __forceinline__ const double *cond(int e) const { return a.cond + (long long)e * a.n_cond; }
-    __device__ __forceinline__ const double *tt(int e) const { return a.t + (long long)e * a.n_t; }
-    __device__ __forceinline__ const double *ob(int e) const { return a.obs + (long long)e * a.n_t; }
+    const double *s_t, *s_obs;  // the data times and observations of all experiments, staged in LDS by the kernel
+    __device__ __forceinline__ const double *tt(int e) const { return s_t + e * a.n_t; }
+    __device__ __forceinline__ const double *ob(int e) const { return s_obs + e * a.n_t; }
     __device__ __forceinline__ void publish(long long idx, double sum, int info) const {
         // visible to the waves of other XCDs while the kernel runs (the early-rejection bound reads the siblings' sums)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.sum_r2) + idx, (unsigned long long)__double_as_longlong(sum),
@@ -367,9 +374,15 @@ struct UserOps {
 
 // Outputs per item: the sum of squared residuals and attempts | cancelled << 29 | failed << 30.
 extern "C" __global__ void __launch_bounds__(256) smc_user_solve_kernel(smc::UserSolveArgs a) {
-    extern __shared__ double s_pool_all[];       // per wave: a ring of 64 started items of UserOps::kPoolWords words
+    extern __shared__ double s_pool_all[];       // per wave: a ring of 64 started items of UserOps::kPoolWords words, then
     double *s_pool = s_pool_all + (threadIdx.x >> 6) * (UserOps::kPoolWords * 64);
-    UserOps ops{a, a.n, a.n_ex, nullptr, 0u};
+    double *s_t = s_pool_all + 4 * (UserOps::kPoolWords * 64), *s_obs = s_t + a.n_ex * a.n_t;   // the data, read by every output
+    for (int i = threadIdx.x; i < a.n_ex * a.n_t; i += blockDim.x) {
+        s_t[i] = a.t[i];
+        s_obs[i] = a.obs[i];
+    }
+    __syncthreads();
+    UserOps ops{a, a.n, a.n_ex, nullptr, 0u, s_t, s_obs};
     smc::solve_persistent(ops, a.queue, s_pool);
 }
 )SRC";
@@ -427,9 +440,9 @@ static std::string build_source(const char *user_source, int n_states, int dim) 
 // compile for gfx950; on failure `log` holds hiprtc's diagnostics
 static bool compile_user(const std::string &src, std::vector<char> &code, std::string &log) {
     hiprtcProgram prog;
-    const char *headers[] = {k_sweep_args_h, k_philox_h, k_solve_sched_h};
-    const char *names[] = {"sweep_args.h", "philox.h", "solve_sched.h"};
-    if (hiprtcCreateProgram(&prog, src.c_str(), "smc_user_model.hip", 3, headers, names) != HIPRTC_SUCCESS) {
+    const char *headers[] = {k_sweep_args_h, k_philox_h, k_solve_sched_h, k_rk45_math_h};
+    const char *names[] = {"sweep_args.h", "philox.h", "solve_sched.h", "rk45_math.h"};
+    if (hiprtcCreateProgram(&prog, src.c_str(), "smc_user_model.hip", 4, headers, names) != HIPRTC_SUCCESS) {
         log = "hiprtcCreateProgram failed";
         return false;
     }
@@ -466,6 +479,11 @@ void user_model_release(smc_ctx *c) {
     c->user = nullptr;
 }
 
+// dynamic LDS of the compiled kernel: four waves' pools of started items, then the data times and observations
+static size_t user_lds_bytes(int n_states, int n_ex, int n_t) {
+    return ((size_t)4 * (2 * n_states + 6) * 64 + (size_t)2 * n_ex * n_t) * sizeof(double);
+}
+
 static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, int64_t n, uint8_t *p0mask, double *lk,
                                bool reject) {
     UserModel *u = (UserModel *)c->user;
@@ -494,7 +512,7 @@ static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, 
     int64_t blocks = (int64_t)c->cu_count * u->blocks_per_cu;
     if (blocks > (chunks + 3) / 4) blocks = (chunks + 3) / 4;
     if (blocks < 1) blocks = 1;
-    const unsigned lds = (unsigned)(4 * (2 * u->n_states + 6) * 64 * sizeof(double));   // four waves' pools of started items
+    const unsigned lds = (unsigned)user_lds_bytes(u->n_states, u->n_ex, u->n_t);
     void *args[] = {&a};
     {
         ScopedTimer tm(c, SMC_T_SOLVE);
@@ -588,7 +606,11 @@ int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const doubl
     }
     {   // occupancy of the compiled kernel with its pool in LDS
         int nb = 0;
-        const size_t lds = (size_t)4 * (2 * n_states + 6) * 64 * sizeof(double);
+        const size_t lds = user_lds_bytes(n_states, n_ex, n_t);
+        if (lds > 150 * 1024) {
+            user_model_release(c);
+            return smc_fail(c, "smc_set_model_user: data set too large for the kernel's LDS table (n_ex * n_t * 16 B + pools > 150 KB)");
+        }
         if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, u->fn, 256, lds) == hipSuccess && nb >= 1) u->blocks_per_cu = nb;
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void *>(u->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -135,11 +135,12 @@ def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_
     (smc_ess_search_global): the back-off grid gamma_old + (1 - gamma_old) * 0.7^k is known in advance, the decision which
     candidate is the first to pass is the reference's own expression on the returned sums."""
     n = s.n_particle
-    fused = _on_device(comm) and s.ess_search != "bisection" and hasattr(engine, "ess_search_global")
+    fused = _on_device(comm) and s.ess_search != "bisection" and getattr(engine, "ess_search_global", None) is not None
     gms, gammas, gamma_after_all = ess_candidates(gamma_old, s)
     if fused:
-        # the first tempering step needs 17-18 candidates (gamma_1 ~ 2e-3 = 0.7^17), later ones fewer than 16
-        first = 2 * chunk if gamma_old == 0.0 else chunk
+        # the first tempering step needs 17-18 candidates (gamma_1 ~ 2e-3 = 0.7^17), later ones sometimes more than 16: a
+        # second 24-us pass is cheaper than a second synchronisation, so every call evaluates 32
+        first = 2 * chunk
         max_lk, sw0, sw20 = engine.ess_search_global(gms[:first], with_max=True)
     else:
         max_lk = _max_lk(engine, comm)                                        # :116
@@ -152,7 +153,7 @@ def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_
     k0 = 0
     while k0 < len(gms):
         if fused:
-            width = (2 * chunk if gamma_old == 0.0 else chunk) if k0 == 0 else 2 * chunk
+            width = 2 * chunk
             part = gms[k0:k0 + width]
             if k0 == 0:
                 sw, sw2 = sw0, sw20

@@ -42,6 +42,8 @@ class HipEngine:
             raise SmcError(f"smc_create: {msg.decode() if msg else 'unknown error'}")
         self.ctx = ctx
         self.model = None
+        if "smc_ess_search_global" in B.MISSING:   # A/B build of an older revision (SMC_HIP_LIB): the driver falls back
+            self.ess_search_global = None
         self._peer_barrier = None
 
     # ---- lifetime ------------------------------------------------------------------------------

@@ -64,8 +64,7 @@ def test_rng_state_json_round_trip(pkg):
 @pytest.mark.parametrize("spread,gamma_old,limit_itr", [(0.5, 0.0, 80), (40.0, 0.0, 80), (3e3, 0.0, 80), (3e5, 0.0, 80),
                                                         (3e9, 0.0, 80), (40.0, 0.3, 80), (3e3, 0.9, 80), (3e9, 0.0, 40)])
 def test_fused_search_equals_the_chunked_search(pkg, O, data, spread, gamma_old, limit_itr):
-    """The back-off search through smc_ess_search_global's shape (maximum + 32 candidates per synchronisation; 16 after the
-    first step) returns exactly what the chunk-by-chunk search returns - gamma, ESS, sums, iteration count, the warning
+    """The back-off search through smc_ess_search_global's shape (maximum + 32 candidates per synchronisation) returns exactly what the chunk-by-chunk search returns - gamma, ESS, sums, iteration count, the warning
     when no candidate passes (Micmem_SMC_main.py:143-144) - for first passing candidates at k = 0, within the first 16,
     between 16 and 32, beyond 32, and never; and it synchronises less often."""
     rs = np.random.RandomState(7)
@@ -80,6 +79,6 @@ def test_fused_search_equals_the_chunked_search(pkg, O, data, spread, gamma_old,
     for k in ("gamma_new", "gm", "ess", "sum_weight", "max_lk", "iters", "warning"):
         assert a[k] == b[k], k
     assert a["syncs"] < b["syncs"]
-    assert a["syncs"] == 1 + max(0, (a["iters"] - (32 if gamma_old == 0.0 else 16) + 31) // 32)
+    assert a["syncs"] == 1 + max(0, (a["iters"] - 32 + 31) // 32)
     assert a["warning"] == (spread == 3e9 and limit_itr == 40)
     print(spread, gamma_old, "first passing candidate:", a["iters"], "synchronisations", a["syncs"], "vs", b["syncs"])
