@@ -445,6 +445,8 @@ def main():
                     help="A/B switch: complete every solve even when its proposal is already certain to be rejected (SMCSettings.early_reject)")
     ap.add_argument("--no-stiff-first", action="store_true",
                     help="A/B switch: hand the (particle, experiment) solves out in plain index order (SMCSettings.stiff_first)")
+    ap.add_argument("--no-in-phase", action="store_true",
+                    help="A/B switch: never let a wave wait for all of its lanes before a hand-out (SMCSettings.in_phase)")
     ap.add_argument("--progress", action="store_true",
                     help="methanation only: one line per sweep on stderr and in gpurun_out/bench_methanation_progress.log")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -464,7 +466,7 @@ def main():
     n_local = args.particles_per_gpu
     n_global = n_local * world
     t, P_obs, S0 = load_mm_data()
-    s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first)
+    s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first, in_phase=not args.no_in_phase)
 
     # SMC_BENCH_DEVICE pins every rank to one device (rehearsing the multi-rank path on a one-GPU box)
     dev = int(os.environ.get("SMC_BENCH_DEVICE", local_rank))

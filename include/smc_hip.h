@@ -148,6 +148,12 @@ int smc_set_early_reject(smc_ctx *ctx, int enable);
  * one-Ray-task-per-particle fan-out (Micmem_likelihood.py:83-87) leaves it to its scheduler too; 0 restores round 2's
  * plain index order (A/B timing, tests). */
 int smc_set_stiff_first(smc_ctx *ctx, int enable);
+/* Michaelis-Menten Metropolis sweeps over a homogeneous population (the previous sweep of the context had fewer than one
+ * (particle, experiment) solve in 20 000 with more than 64 RK45 attempts - counted on the device) run their waves IN PHASE
+ * (default: on): a wave waits up to 12 attempts for all 64 lanes to finish before it starts its next 64 items, so that the
+ * lanes stay at the same point of their trajectories and the dense-output loop runs as long as the average lane needs, not
+ * the busiest (csrc/solve_sched.h).  Scheduling only: no result changes.  0 = hand out as soon as 24 lanes are idle, always. */
+int smc_set_in_phase(smc_ctx *ctx, int enable);
 /* Parity mode of the Michaelis-Menten step controller (default: off).  SciPy evaluates error_norm ** -0.2 (rk.py:155,169)
  * and x ** (1 / 5) (common.py:130) with libm's pow and the DOUBLE exponents -0.2 / 0.2 (= 1/5 + 1.1e-17).  The fast
  * device form (hardware log2 / exp2 seed + one correction, <= 1.5 ulp about the fifth root) differs from that in the last

@@ -150,6 +150,11 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
 // solve: persistent waves, lane-level dynamic scheduling (solve_sched.h) of Michaelis-Menten items
 // ---------------------------------------------------------------------------------------------
 constexpr int kSolveBlock = 256;   // 4 waves
+// An item that needed more attempts than this is "long": the accept kernel counts them, and a Metropolis sweep whose
+// predecessor had (almost) none runs its waves in phase (SolveArgs::patience, solve_sched.h).  A posterior-like solve takes
+// 19 +- a few attempts, the stragglers of a prior-like population hundreds to thousands.
+constexpr int kLongItemAttempts = 64;
+constexpr int kInPhasePatience = 12;
 constexpr int kPoolWords = 15;     // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer
 
 struct SolveArgs {              // everything the attempt loops do not touch stays behind a pointer (RejectArgs, StiffList)
@@ -163,6 +168,7 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     const RejectArgs *rej;      // exact early rejection (Metropolis sweeps only; nullptr: off): see mm_certainly_rejected()
     const int32_t *stiff_list;  // particles whose solves are handed out first (nullptr: none), and how many
     const unsigned *stiff_count;
+    int patience;               // solve_sched.h: attempts a wave waits for all its lanes before a hand-out (homogeneous sweeps)
 };
 
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
@@ -242,6 +248,7 @@ struct MMOps {
     const int32_t *list;
     unsigned n_list;
     double rtol, atol;
+    int patience;
 
     __device__ __forceinline__ int start(long long p, int e, bool from_list, Item &nb) const {
         nb.out_idx = (int64_t)e * a.n + p;
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     // the wave's pool of STARTED items (solve_sched.h): a ring of 64 slots of kPoolWords words
     double *s_pool = s_S0 + ((n_ex + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kPoolWords * kWave);
     const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)*a.stiff_count) : 0u;
-    MMOps<WRITE_PRED, EXACT> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff, mm.rtol, mm.atol};
+    MMOps<WRITE_PRED, EXACT> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff, mm.rtol, mm.atol, a.patience};
     solve_persistent(ops, a.queue, s_pool);
 }
 
@@ -377,7 +384,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                  uint8_t *__restrict__ dbg_r) {
     __shared__ unsigned long long s_cnt[4][4];
     __shared__ double s_mom[4][9];
-    unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0;
+    unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0, long_items = 0;
     // moments of the SELECTED particles about mh.moment_shift (MODE 1, fused iteration): sum y, sum y y^T (upper), y = x - shift
     double m0 = 0, m1 = 0, m2 = 0, c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
     const bool acc_mom = (MODE == 1) && mh.moment_rows != nullptr;
@@ -407,6 +414,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                 lk2 += mm_loglik_term(c0, sum_r2[(int64_t)k * n + p], s2);          // :70-73
                 const int fl = info[(int64_t)k * n + p];
                 attempts += (unsigned)(fl & kInfoAttemptsMask);
+                long_items += (unsigned)(fl & kInfoAttemptsMask) > (unsigned)kLongItemAttempts;
                 pf |= (unsigned)(fl >> 30) & 1u;
                 cancelled = cancelled || (fl & kInfoCancelled) != 0;
             }
@@ -456,6 +464,8 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
         }
     }
     // integer reductions (order-independent): wave shuffles, LDS across the 4 waves, one atomic per block
+    for (int off = 32; off > 0; off >>= 1) long_items += __shfl_down(long_items, off);
+    if ((threadIdx.x & 63) == 0 && long_items) atomicAdd(&counters->long_items, long_items);
     for (int off = 32; off > 0; off >>= 1) {
         attempts += __shfl_down(attempts, off);
         failed += __shfl_down(failed, off);
@@ -518,7 +528,7 @@ static StiffList next_stiff_list(smc_ctx *ctx) {
 }
 
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
-                         const StiffList &sl, bool queue_cleared = false, bool reject = false) {
+                         const StiffList &sl, bool queue_cleared = false, bool reject = false, int patience = 0) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
     a.theta = theta;
@@ -532,6 +542,7 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.rej = reject ? ctx->d_reject : nullptr;
     a.stiff_list = sl.particles;
     a.stiff_count = sl.count;
+    a.patience = patience;
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
     const bool exact = ctx->exact_pow != 0;
@@ -591,7 +602,11 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     mh.stiff = next_stiff_list(ctx);
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
-    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.stiff, mh.zero_queue != nullptr, reject);
+    // in phase (solve_sched.h) when the previous Metropolis sweep of this context had fewer than 1 long item in 20 000
+    const int patience = (ctx->in_phase != 0 && ctx->last_sweep_items > 0 &&
+                          ctx->last_sweep_long_items * 20000 < ctx->last_sweep_items) ? kInPhasePatience : 0;
+    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.stiff, mh.zero_queue != nullptr, reject, patience);
+    ctx->pending_sweep_items = n * ctx->mm.n_ex;
     ctx->moment_rows_n = mh.moment_rows ? (int)finish_grid(n) : 0;
     hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        P.theta, P.stride, n, ctx->d_sum_r2, ctx->d_info, ctx->d_p0, F.lk, F.theta, F.stride, ctx->r_ac,

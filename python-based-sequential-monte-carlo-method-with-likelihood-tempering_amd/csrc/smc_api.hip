@@ -393,6 +393,12 @@ int smc_set_exact_pow(smc_ctx *c, int enable) {
     return 0;
 }
 
+int smc_set_in_phase(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    c->in_phase = enable != 0;
+    return 0;
+}
+
 int smc_set_stiff_first(smc_ctx *c, int enable) {
     if (!c) return fail(nullptr, "NULL context");
     c->stiff_first = enable != 0;
@@ -508,6 +514,11 @@ static int counters_begin(smc_ctx *c) {
 static int counters_end(smc_ctx *c) {
     HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(SweepCounters), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->model_kind == 1 && c->pending_sweep_items > 0) {   // what the next Metropolis sweep's in-phase decision looks at
+        c->last_sweep_items = c->pending_sweep_items;
+        c->last_sweep_long_items = (int64_t)c->h_counters->long_items;
+        c->pending_sweep_items = 0;
+    }
     if (c->model_kind == 2) {   // every (particle, experiment) item the sweep asked for must have been solved exactly once
         const SweepCounters &k = *c->h_counters;
         if (k.completed_solves + k.cancelled_solves != k.expected_solves || k.unsolved_items != 0 || k.wave_split != 0) {

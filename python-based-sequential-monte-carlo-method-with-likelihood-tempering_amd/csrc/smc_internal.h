@@ -98,6 +98,7 @@ struct SweepCounters {  // device-side integer counters (order-independent atomi
     // completed == expected and the other two are zero (checked on the host after every sweep).
     unsigned long long expected_solves, completed_solves, unsolved_items, wave_split;
     unsigned long long cancelled_solves;   // solves not started because their proposal was already certain to be rejected
+    unsigned long long long_items;         // Michaelis-Menten: items that needed more than kLongItemAttempts attempts (mm_kernels.hip)
 };
 
 struct EventPair {
@@ -167,6 +168,8 @@ struct smc_ctx {
     unsigned *d_stiff_count = nullptr;
     int stiff_parity = 0;
     int stiff_first = 1;                   // hand the predictably long solves out first (smc_set_stiff_first)
+    int in_phase = 1;                      // let homogeneous Metropolis sweeps run their waves in phase (solve_sched.h: patience)
+    int64_t last_sweep_items = 0, last_sweep_long_items = 0, pending_sweep_items = 0;   // of the last finished MM Metropolis sweep
     int exact_pow = 0;                     // parity mode: correctly rounded pow(x, -0.2) in the step controller (smc_set_exact_pow)
     bool solve_lds_raised = false;         // hipFuncAttributeMaxDynamicSharedMemorySize raised on THIS device
     int cu_count = 0, solve_blocks_per_cu = 0;

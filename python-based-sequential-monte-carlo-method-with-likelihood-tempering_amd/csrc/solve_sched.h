@@ -34,6 +34,7 @@
 //   int  attempt(Item &)                 one step attempt; 0 = still running, anything else = finished / failed
 //   void finish(Item &, int status)      publish the result
 //   Item broadcast(const Item &, int src)   the item of lane src in every lane (v_readlane on every field)
+//   int patience                         attempts a wave waits for ALL its lanes before a hand-out (0: none; see kRefillAt below)
 //   bool reject_enabled()                wave-uniform
 //   bool certainly_rejected(const Item &)   exact bound; may read results other waves have published
 //   void cancel(Item &)                  publish "stopped: its proposal is rejected"
@@ -72,6 +73,18 @@ constexpr int kPoolRefillFree = SMC_POOL_FREE;   // free pool slots that trigger
 // items, so that at the end of the sweep a wave rarely holds two survivors and can run its last one on wave-uniform operands.
 constexpr int kStiffPerChunk = SMC_STIFF_PER_CHUNK;
 static_assert(kStiffPerChunk >= 1 && kStiffPerChunk <= 64, "a list chunk is started by one wave at once");
+// Staying IN PHASE (Ops::patience).  In the posterior phase the 64 items a wave starts together (consecutive particles, one
+// experiment) take the same number of attempts to within a few.  If the wave hands new items to the first kRefillAt
+// finishers at once, those lanes run out of phase with the rest from then on - and the dense-output loop of EVERY attempt
+// then runs as long as the lane that happens to be in the late, large-step part of its trajectory needs (5 outputs per step)
+// although the average lane needs 2: 3.1 wave-iterations per attempt where the lanes' mean is 2.2 (SQ counters, DESIGN.md
+// 4.1 item 8).  Letting the whole wave restart together costs the early finishers a few attempts of waiting and buys that
+// back: steady-state sweep 1.33 -> 1.21 ms with a patience of 4 attempts, 1.17 ms with 16 (profiles/r03_ab_patience.log).
+// Waiting idles the wave behind every straggler of a prior-like population, though (whole run 93 -> 95 / 102 ms when it is
+// unconditional), and the finishers of a posterior-like wave do not arrive sharply enough for the wave to tell the two
+// situations apart by itself (tried: "wait while >= 8 more lanes finished in the last attempt", "wait if 24 lanes finished
+// within 4 attempts of the first": no gain).  So the HOST decides per sweep, from the device-counted number of long items
+// of the previous sweep, and passes the patience in: 0 = hand out as soon as kRefillAt lanes are idle.
 constexpr int kRejectCheckEvery = 512;        // attempts between two looks at the rejection bound (a look costs about five)
 constexpr int kStartStarted = 0, kStartDone = 1, kStartSkipped = 2;
 
@@ -278,7 +291,8 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
         // attempts of the live lanes until kRefillAt lanes are idle (they then take items from the pool, which is refilled
         // above when it runs low): a tight inner loop (item state stays in its registers, one ballot and one scalar branch
         // per attempt) - the scheduling logic above runs once per hand-out, not once per attempt
-        int idle_now;
+        const int patience = ops.patience;   // attempts to go on waiting for ALL lanes once kRefillAt are idle (see above)
+        int idle_now, waited = 0;
         do {
             SMC_ISA_MARK("bulk_attempt");
             if (live) {
@@ -289,7 +303,8 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
                 }
             }
             idle_now = kWave - __popcll(__ballot(live));
-        } while (idle_now < kRefillAt);
+            waited += (idle_now >= kRefillAt);                      // scalar
+        } while (idle_now < kRefillAt || (idle_now < kWave && waited <= patience));
     }
 }
 

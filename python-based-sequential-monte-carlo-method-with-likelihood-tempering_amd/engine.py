@@ -187,6 +187,12 @@ class HipEngine:
             return
         self._ck(self.L.smc_set_exact_pow(self.ctx, int(bool(enable))), "smc_set_exact_pow")
 
+    def set_in_phase(self, enable=True):
+        """Let homogeneous Michaelis-Menten Metropolis sweeps run their waves in phase (include/smc_hip.h: smc_set_in_phase)."""
+        if "smc_set_in_phase" in B.MISSING:        # A/B build of an older revision (SMC_HIP_LIB)
+            return
+        self._ck(self.L.smc_set_in_phase(self.ctx, int(bool(enable))), "smc_set_in_phase")
+
     def set_stiff_first(self, enable=True):
         """Hand the predictably long Michaelis-Menten solves out first (include/smc_hip.h: smc_set_stiff_first)."""
         if "smc_set_stiff_first" in B.MISSING:     # A/B build of a revision before the stiff list (SMC_HIP_LIB)
