@@ -314,6 +314,7 @@ def bench_methanation(args):
         return bench_methanation_sweeps(args, pkg, eng, s, n)
     comm = make_comm(pkg, eng, rank, world)
     s.early_reject = not args.no_early_reject
+    s.stiff_first = not args.no_stiff_first      # methanation: adaptive experiment order of the early-rejection sweeps
     if args.progress and rank == 0:      # a config-4 run lasts many minutes: one line per sweep on stderr (and in a file the
         t_begin = time.perf_counter()    # GPU box's watchdog can see), so that a long run does not look hung
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

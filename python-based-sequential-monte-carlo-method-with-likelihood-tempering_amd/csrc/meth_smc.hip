@@ -7,6 +7,9 @@
 //   MH iteration                       SMC_methanation_main.py:295-391 (the taken branch: normal_pred False)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "meth_dae_wave.h"
 #include "meth_dae_elem.h"
 #include "philox.h"
@@ -28,6 +31,35 @@ constexpr int kStatusCancelled = -2;   // not solved: the proposal was already c
 // non-negative square - can only raise the result.
 __device__ __forceinline__ double meth_acc_step(double acc, double d) { return acc + d * d; }
 __device__ __forceinline__ double meth_loglike_step(double total, double c, double acc, double l) { return total + (c * acc - l); }
+
+// Which experiments tell most about a proposal?  Per experiment, over the solved items of a sweep, the mean of
+// log(1 + sum over the species of (flow - obs)^2) - robust against the 1e8 of a failed solve's sentinel flows.  The NEXT
+// Metropolis sweep solves the experiments in descending order of this misfit (launch_solves): a proposal that is going to be
+// rejected then accumulates its damning residuals first and the early-rejection bound cancels its remaining solves sooner.
+// Any order gives the same results (the likelihood is always summed in index order); the order only decides how soon.
+__global__ void __launch_bounds__(256)
+meth_experiment_stats_kernel(const double *__restrict__ flows, const int *__restrict__ status, const uint8_t *__restrict__ p0mask,
+                             const double *__restrict__ obs, int64_t n, int n_data, double *__restrict__ stat /* 2 x n_data */) {
+    extern __shared__ double s_stat[];
+    for (int i = threadIdx.x; i < 2 * n_data; i += blockDim.x) s_stat[i] = 0.0;
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        if (p0mask && p0mask[p] == 0) continue;
+        for (int e = 0; e < n_data; ++e) {
+            if (status[p * n_data + e] < 0) continue;        // not solved (cancelled)
+            double t = 0.0;
+            for (int i = 0; i < 5; ++i) {
+                const double d = flows[(p * n_data + e) * 5 + i] - obs[i * n_data + e];
+                t += d * d;
+            }
+            atomicAdd(&s_stat[e], log1p(t));
+            atomicAdd(&s_stat[n_data + e], 1.0);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * n_data; i += blockDim.x)
+        if (s_stat[i] != 0.0) atomicAdd(&stat[i], s_stat[i]);
+}
 
 // the live proposals of an MH sweep, compacted (order irrelevant); queue[1] counts them
 __global__ void meth_livelist_kernel(const uint8_t *__restrict__ p0mask, int64_t n, int64_t *__restrict__ list,
@@ -103,11 +135,12 @@ __device__ __attribute__((noinline)) bool meth_certainly_rejected(const RejectAr
 __global__ void __launch_bounds__(64)
 meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
                           const int64_t *__restrict__ live, double *flows, int *status, const RejectArgs *__restrict__ rej,
+                          const int *__restrict__ order /* experiment solved at rank k, or nullptr = k */,
                           SweepCounters *__restrict__ counters, unsigned long long *__restrict__ queue) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const DViewE D{lds + kLdsD, lane};
-    // EXPERIMENT-MAJOR order: position q = e * n_live + j is experiment e of the j-th live particle, so that the experiments
+    // EXPERIMENT-MAJOR order: position q = k * n_live + j is the experiment of rank k of the j-th live particle, so that the experiments
     // of one proposal come up one after the other, n_live positions apart, and the later ones can be cancelled on the
     // strength of the earlier ones (meth_certainly_rejected).  Which experiment is solved first cannot change a result.
     const int64_t n_live = live ? (int64_t)queue[1] : n;
@@ -117,8 +150,9 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
     for (int64_t it = 0; it <= count; ++it) {
         const int64_t pos = wave_dequeue(&queue[0], lane, split);
         if (pos >= count) break;
-        const int e = (int)(pos / n_live);
-        const int64_t j = pos - (int64_t)e * n_live;
+        const int e_rank = (int)(pos / n_live);
+        const int64_t j = pos - (int64_t)e_rank * n_live;
+        const int e = order ? order[e_rank] : e_rank;           // most informative experiments first (meth_experiment_stats_kernel)
         const int64_t particle = live ? live[j] : j;
         const int64_t w = particle * m.n_data + e;
         if (rej) {
@@ -365,8 +399,29 @@ static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int
                            ctx->d_mwork, ctx->d_queue);
         live = ctx->d_mwork;
     }
+    const int *order = nullptr;
+    if (reject && ctx->stiff_first && ctx->d_morder) {
+        if (ctx->mstat_pending) {   // the misfit statistics the previous Metropolis sweep left behind -> this sweep's order
+            std::vector<double> st(2 * (size_t)m.n_data);
+            if (hipMemcpyAsync(st.data(), ctx->d_mstat, st.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                hipStreamSynchronize(ctx->stream) == hipSuccess) {
+                std::vector<int> ord(m.n_data);
+                for (int e = 0; e < m.n_data; ++e) ord[e] = e;
+                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+                    const double ma = st[m.n_data + a] > 0 ? st[a] / st[m.n_data + a] : 0.0;
+                    const double mb = st[m.n_data + b] > 0 ? st[b] / st[m.n_data + b] : 0.0;
+                    return ma > mb;
+                });
+                (void)hipMemcpyAsync(ctx->d_morder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);   // ord is a local
+                ctx->morder_valid = true;
+            }
+            ctx->mstat_pending = false;
+        }
+        if (ctx->morder_valid) order = ctx->d_morder;
+    }
     hipLaunchKernelGGL(meth_particles_dae_kernel, dim3((unsigned)nwaves), dim3(64), kLdsDoubles * sizeof(double), ctx->stream,
-                       m, theta, stride, n, live, ctx->d_mflows, ctx->d_mstatus, reject ? ctx->d_reject : nullptr,
+                       m, theta, stride, n, live, ctx->d_mflows, ctx->d_mstatus, reject ? ctx->d_reject : nullptr, order,
                        ctx->d_counters, ctx->d_queue);
 }
 
@@ -410,6 +465,14 @@ void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     launch_generic_propose(ctx, n, mh);
     launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0, reject);
     if (ctx->launch_failed) return;
+    if (reject && ctx->stiff_first && ctx->d_mstat) {   // misfit per experiment of THIS sweep's proposals: the next sweep's order
+        (void)hipMemsetAsync(ctx->d_mstat, 0, 2 * (size_t)ctx->meth.n_data * sizeof(double), ctx->stream);
+        const int64_t g = (n + 255) / 256;
+        hipLaunchKernelGGL(meth_experiment_stats_kernel, dim3((unsigned)(g < 512 ? g : 512)), dim3(256),
+                           2 * (size_t)ctx->meth.n_data * sizeof(double), ctx->stream, ctx->d_mflows, ctx->d_mstatus, ctx->d_p0,
+                           ctx->meth.obs, n, ctx->meth.n_data, ctx->d_mstat);
+        ctx->mstat_pending = true;
+    }
     hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
                        P.theta, P.stride, n, ctx->d_mflows, ctx->d_mstatus, ctx->d_p0, ctx->d_counters, ctx->d_mlk2);
     launch_generic_accept(ctx, n, mh, ctx->d_mlk2);

@@ -223,6 +223,8 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_mlk2);
     (void)hipFree(c->d_mstatus);
     (void)hipFree(c->d_mwork);
+    (void)hipFree(c->d_mstat);
+    (void)hipFree(c->d_morder);
     (void)hipFree(c->d_hb_theta);
     (void)hipFree(c->d_hb_lk);
     (void)hipFree(c->d_hb_pred);
@@ -307,6 +309,11 @@ int smc_set_model_methanation(smc_ctx *c, const double *cond, const double *gues
     HIPC(c, hipMalloc(&c->d_mlk2, (size_t)c->n_local * 8));
     HIPC(c, hipMalloc(&c->d_mstatus, (size_t)c->n_local * n_data * sizeof(int)));
     HIPC(c, hipMalloc(&c->d_mwork, (size_t)c->n_local * n_data * sizeof(int64_t)));
+    (void)hipFree(c->d_mstat); (void)hipFree(c->d_morder);
+    c->d_mstat = nullptr; c->d_morder = nullptr;
+    c->mstat_pending = c->morder_valid = false;
+    HIPC(c, hipMalloc(&c->d_mstat, 2 * (size_t)n_data * sizeof(double)));
+    HIPC(c, hipMalloc(&c->d_morder, (size_t)n_data * sizeof(int)));
     HIPC(c, hipMemcpyAsync(c->d_mcond, cond, (size_t)n_data * 10 * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->d_mguess, guess, (size_t)n_data * 357 * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->d_mobs, obs, (size_t)n_data * 5 * 8, hipMemcpyHostToDevice, c->stream));

@@ -1,0 +1,36 @@
+#!/bin/bash
+# final profile collection of the round (one box): every step appends to gpurun_out/final/progress.log
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/final
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+log() { echo "$(date +%T) $*" >> $O/progress.log; }
+set -e
+log "bench 20/5 (clean)"
+timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_mm.json 2> $O/bench_mm.err
+log "kernel stats"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_mm_under_rocprof.json 2> $O/stats.err
+log "pmc fetch"
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
+log "pmc write"
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_WAVES SQ_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS"; do
+  i=$((i+1))
+  log "sq pass $i (steady state)"
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sq$i -- python3 $R/tools/steady_state.py 1000000 1 > $O/sq$i.log 2>&1
+  log "sq pass $i (whole run)"
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sqrun$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/sqrun$i.log 2>&1
+done
+cd $R
+log "no early reject"
+timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-early-reject > $O/bench_mm_no_early_reject.json 2> $O/ner.err
+log "1e7"
+timeout -k 10 300 python3 bench.py --particles-per-gpu 10000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_mm_n1e7.json 2> $O/n1e7.err
+log "1e8"
+timeout -k 10 400 python3 bench.py --particles-per-gpu 100000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_mm_n1e8.json 2> $O/n1e8.err
+log "steady + tail"
+timeout -k 10 200 python3 tools/steady_state.py 1000000 1 > $O/steady.log 2>&1
+timeout -k 10 200 python3 tools/steady_state.py 10000000 1 >> $O/steady.log 2>&1
+timeout -k 10 200 python3 tools/tail_latency.py > $O/tail.log 2>&1
+log "done"
