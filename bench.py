@@ -113,8 +113,8 @@ def cpu_baseline(sample_seconds_target=15.0):
 
 
 # the translation unit of the Michaelis-Menten kernels: mm_kernels.hip and everything it includes
-MM_KERNEL_SOURCES = ("csrc/mm_kernels.hip", "csrc/mm_rk45.h", "csrc/philox.h", "csrc/prior.h", "csrc/smc_internal.h",
-                     "include/smc_hip.h")
+MM_KERNEL_SOURCES = ("csrc/mm_kernels.hip", "csrc/mm_rk45.h", "csrc/rk45_math.h", "csrc/pow_fifth_exact.h", "csrc/solve_sched.h",
+                     "csrc/sweep_args.h", "csrc/philox.h", "csrc/prior.h", "csrc/smc_internal.h", "include/smc_hip.h")
 
 
 def kernel_source_sha(root=None):
@@ -539,7 +539,7 @@ def main():
         ach_tflops = flop_per_launch / (solve_ms * 1e-3) / 1e12
         hbm_gbps = HBM_BYTES_PER_PARTICLE_SOLVE * n_local / (solve_ms * 1e-3) / 1e9
         ess_ms = timing["ess"]["ms"]
-        traffic, traffic_note = measured_traffic("void smc::mm_solve_kernel<false>", n_local)
+        traffic, traffic_note = measured_traffic("void smc::mm_solve_kernel<false, false>", n_local)
         valu, valu_note = measured_valu_issue(n_local)
         ess_l = timing["ess"]["launches"]
         ess_avg_ms = ess_ms / max(1, ess_l)
@@ -563,7 +563,7 @@ def main():
             "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(),
             "kernel_ms": {k: v for k, v in timing.items()},
             "steady_state": steady,
-            "roofline": {"kernel": "mm_solve_kernel<false> (persistent RK45 solve, lane-level dynamic scheduling)",
+            "roofline": {"kernel": "mm_solve_kernel<false, false> (persistent RK45 solve, lane-level dynamic scheduling: csrc/solve_sched.h)",
                          "bound": "mfma",
                          "bound_note": "compute roof: the kernel issues FP64 vector FMAs (no contraction larger than 3x3, so "
                                        "MFMA is unused); on MI355X the FP64 matrix and vector peaks coincide (78.6 TFLOP/s), "

@@ -1,5 +1,7 @@
 #!/bin/bash
-# final profile collection of the round (one box): every step appends to gpurun_out/final/progress.log
+# Final profile collection of a round on ONE box (gpurun --timeout 1200 -- 'bash tools/final_profiles.sh'): every step appends to
+# gpurun_out/final/progress.log (the box's watchdog sees the run is alive); tools/collect_profiles.py condenses the result
+# into profiles/rNN_*.  rocprofv3: program directly after `--`, counters in their own passes (--kernel-trace only).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
@@ -22,6 +24,8 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_
   log "sq pass $i (whole run)"
   timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sqrun$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/sqrun$i.log 2>&1
 done
+log "methanation N = 1024 under rocprof"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/meth_stats -o run -- python3 $R/bench.py --workload methanation --particles-per-gpu 1024 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_methanation_n1024_under_rocprof.json 2> $O/meth_stats.err
 cd $R
 log "no early reject"
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-early-reject > $O/bench_mm_no_early_reject.json 2> $O/ner.err
@@ -29,8 +33,9 @@ log "1e7"
 timeout -k 10 300 python3 bench.py --particles-per-gpu 10000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_mm_n1e7.json 2> $O/n1e7.err
 log "1e8"
 timeout -k 10 400 python3 bench.py --particles-per-gpu 100000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_mm_n1e8.json 2> $O/n1e8.err
-log "steady + tail"
+log "steady + tail + user model"
 timeout -k 10 200 python3 tools/steady_state.py 1000000 1 > $O/steady.log 2>&1
 timeout -k 10 200 python3 tools/steady_state.py 10000000 1 >> $O/steady.log 2>&1
 timeout -k 10 200 python3 tools/tail_latency.py > $O/tail.log 2>&1
+timeout -k 10 200 python3 tools/user_model_bench.py 200000 > $O/user_model_bench.log 2>&1
 log "done"
