@@ -142,7 +142,7 @@ int smc_set_prior_mode(smc_ctx *ctx, int mode);
  * capture therefore switches the feature off).  It removes the long solves that dominate the early tempering steps:
  * they are proposals with Vmax/Km in the thousands whose other experiments already rule them out. */
 int smc_set_early_reject(smc_ctx *ctx, int enable);
-/* Michaelis-Menten sweeps hand the predictably long solves (Vmax > 250 Km: RK45 runs on its stability limit for ~3.7 Vmax/Km
+/* Michaelis-Menten sweeps hand the predictably long solves (Vmax > 60 Km: RK45 runs on its stability limit for ~3.7 Vmax/Km
  * attempts) out BEFORE the index-ordered items (default: on), so that the serial chain that bounds a sweep starts at its
  * beginning.  The order in which independent (particle, experiment) solves run changes no result - the reference's
  * one-Ray-task-per-particle fan-out (Micmem_likelihood.py:83-87) leaves it to its scheduler too; 0 restores round 2's

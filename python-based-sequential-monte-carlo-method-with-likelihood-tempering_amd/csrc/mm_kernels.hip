@@ -51,11 +51,18 @@ constexpr double kSumCancelled = -1.0;
 // 10^3 attempts of a 10^6-particle prior sample has r > 269): a serial chain of up to 8e4 attempts = 35 ms that no amount
 // of parallelism shortens.  What CAN be chosen is when it starts.  Handed out in index order, the chain that bounds a
 // sweep began wherever the queue happened to reach it - up to a whole bulk pass (1.3 ms of a 1.7 ms Metropolis sweep,
-// 4 ms of the initial sweep) late.  Particles above the threshold are therefore collected into a list while the proposal
+// 4 ms of the initial sweep) late.  Particles above a threshold of that ratio are therefore collected into a list while the proposal
 // is formed (or by mm_stiff_scan_kernel before a plain likelihood sweep) and mm_solve_kernel hands that list out before
 // the index-ordered items.  The order in which independent items are solved cannot change any result - the reference's
 // own fan-out (one Ray task per particle, Micmem_likelihood.py:83-87) leaves it to the scheduler as well.
-constexpr double kStiffRatio = 250.0;
+// Threshold: every solve above 10^3 attempts has Vmax/Km > 269, but the sweeps of the middle of a run are bounded by chains
+// of a few hundred attempts; handing out everything above ~220 attempts first is longest-first scheduling for them too.
+// Whole run at 10^6 particles, one box (profiles/r03_ab_stiff_ratio.log): 1000 -> 94.5 ms, 250 -> 92.4, 120 -> 90.7, 60 -> 89.8,
+// 30 -> 91.2, 15 -> 94.0, 8 -> 97.1 (the list then holds a third of the prior population and its 16-entry chunks cost dequeues).
+#ifndef SMC_STIFF_RATIO
+#define SMC_STIFF_RATIO 60.0
+#endif
+constexpr double kStiffRatio = SMC_STIFF_RATIO;
 __device__ __forceinline__ bool mm_is_stiff(double Vmax, double Km) { return Km > 0.0 && Vmax > kStiffRatio * Km; }
 // One atomic per stiff lane on purpose: no cross-lane read follows it, so it is correct whether or not the compiler's
 // atomic optimiser folds the wave's atomics into one.  Every particle is appended at most once: the list cannot overflow.

@@ -1136,8 +1136,8 @@ def test_stiff_first_handout_is_bit_identical_to_index_order(pkg, O, data, n, st
     rs = np.random.RandomState(n)
     th = rs.uniform(0.05, 10, (n, 3))
     k = int(round(n * stiff_share))
-    th[:k, 1] = th[:k, 0] / 10.0 ** rs.uniform(2.5, 3.2, k)             # Vmax / Km = 300 ... 1600: on the list
-    th[k:, 1] = np.maximum(th[k:, 1], th[k:, 0] / 200.0)               # below the threshold of 250
+    th[:k, 1] = th[:k, 0] / 10.0 ** rs.uniform(2.0, 3.2, k)             # Vmax / Km = 100 ... 1600: on the list
+    th[k:, 1] = np.maximum(th[k:, 1], th[k:, 0] / 50.0)                # below the threshold of 60
     rs.shuffle(th)
     lk_ref, _, info_ref = O.mm_loglik_batch(th, data)
     noise = rs.standard_normal((n, 3)) * np.array([0.3, 0.001, 0.3])
