@@ -167,8 +167,10 @@ __device__ __forceinline__ RkStages rk_attempt_core(double y, double k0, double 
     s.k5 = mm_rhs_t<LEAN>(y + (k0 * A61 + s.k1 * A62 + s.k2 * A63 + s.k3 * A64 + s.k4 * A65) * h, negVmax, Km);
     s.y_new = y + h * (k0 * B1 + s.k2 * B3 + s.k3 * B4 + s.k4 * B5 + s.k5 * B6);
     s.k6 = mm_rhs_t<LEAN>(s.y_new, negVmax, Km);
-    const double ay = fabs(y), ayn = fabs(s.y_new);
-    const double scale = atol + ((ay > ayn || ay != ay) ? ay : ayn) * rtol;
+    // np.maximum(|y|, |y_new|) propagates NaN, v_max_f64 returns the other operand - and it makes no difference to the one
+    // value that is used, error_norm: a NaN y makes k0, a NaN y_new makes k6 and with it err NaN whatever the scale is.  One
+    // instruction instead of two compares, an or and two selects, in every attempt.
+    const double scale = atol + fmax(fabs(y), fabs(s.y_new)) * rtol;
     const double err = (k0 * E1 + s.k2 * E3 + s.k3 * E4 + s.k4 * E5 + s.k5 * E6 + s.k6 * E7) * h;
     s.error_norm = fabs(mm_div<LEAN>(err, scale));
     return s;
@@ -194,8 +196,7 @@ __device__ __forceinline__ RkStages rk_attempt_core_exact(double y, double k0, d
     s.y_new = SMC_A(y, SMC_M(h, SMC_A(SMC_A(SMC_A(SMC_A(SMC_M(k0, B1), SMC_M(s.k2, B3)), SMC_M(s.k3, B4)), SMC_M(s.k4, B5)),
                                       SMC_M(s.k5, B6))));
     s.k6 = mm_rhs(s.y_new, negVmax, Km);
-    const double ay = fabs(y), ayn = fabs(s.y_new);
-    const double scale = SMC_A(atol, SMC_M((ay > ayn || ay != ay) ? ay : ayn, rtol));
+    const double scale = SMC_A(atol, SMC_M(fmax(fabs(y), fabs(s.y_new)), rtol));   // see rk_attempt_core on the NaN case
     const double err = SMC_M(SMC_A(SMC_A(SMC_A(SMC_A(SMC_A(SMC_M(k0, E1), SMC_M(s.k2, E3)), SMC_M(s.k3, E4)), SMC_M(s.k4, E5)),
                                          SMC_M(s.k5, E6)), SMC_M(s.k6, E7)), h);
     s.error_norm = fabs(err / scale);
@@ -231,6 +232,34 @@ __device__ __forceinline__ void mm_dense_outputs(MMItem &it, const double2 *s_tp
     it.t_next = t_next;
 }
 
+// The dense output of an accepted step that covers data times: Q = K.T.dot(P) (rk.py:179), then mm_dense_outputs.
+template <bool WRITE_PRED, int DIV>
+__device__ __forceinline__ void mm_attempt_outputs(MMItem &it, const double2 *s_tp, const RkStages &st, double k0, double t_old,
+                                                   double t_new, double y_old, double *pred) {
+    const double k2 = st.k2, k3 = st.k3, k4 = st.k4, k5 = st.k5, k6 = st.k6;
+    // P[1][:] = 0 and P[j][0] = 0 for j > 0
+    const double Q0 = k0;
+    const double Q1 = k0 * (-8048581381.0 / 2820520608) + k2 * (131558114200.0 / 32700410799) +
+                      k3 * (-1754552775.0 / 470086768) + k4 * (127303824393.0 / 49829197408) +
+                      k5 * (-282668133.0 / 205662961) + k6 * (40617522.0 / 29380423);
+    const double Q2 = k0 * (8663915743.0 / 2820520608) + k2 * (-68118460800.0 / 10900136933) +
+                      k3 * (14199869525.0 / 1410260304) + k4 * (-318862633887.0 / 49829197408) +
+                      k5 * (2019193451.0 / 616988883) + k6 * (-110615467.0 / 29380423);
+    const double Q3 = k0 * (-12715105075.0 / 11282082432) + k2 * (87487479700.0 / 32700410799) +
+                      k3 * (-10690763975.0 / 1880347072) + k4 * (701980252875.0 / 199316789632) +
+                      k5 * (-1453857185.0 / 822651844) + k6 * (69997945.0 / 29380423);
+    const double hd = t_new - t_old;  // RkDenseOutput.__init__ (rk.py:555)
+    // x = (t_eval - t_old) / h (rk.py:566) by the six-operation division when its operands are safely inside the
+    // normal range: h itself, and the numerator, which is either 0 (t_eval == t_old, first step only), or t_eval
+    // (t_old == 0: smc_set_model_mm admits only data times that are 0 or >= 2^-400 in magnitude), or at least one
+    // ulp of |t_old| >= 2^-400.  Two copies of the loop rather than a select per output.
+    const bool lean_x = (DIV != kDivIeee) && hd >= 0x1p-400 && hd <= 0x1p400 && (t_old == 0.0 || fabs(t_old) >= 0x1p-400);
+    if (lean_x)
+        mm_dense_outputs<WRITE_PRED, true>(it, s_tp, t_old, t_new, hd, y_old, Q0, Q1, Q2, Q3, pred);
+    else
+        mm_dense_outputs<WRITE_PRED, false>(it, s_tp, t_old, t_new, hd, y_old, Q0, Q1, Q2, Q3, pred);
+}
+
 // One step attempt.  Returns 0 while the item is still running, 1 when it finished (t reached
 // t_bound), 2 when it failed (step size underflow, rk.py:133-134; SciPy status -1).
 template <bool WRITE_PRED, int DIV = kDivLean6, bool EXACT = false>
@@ -240,8 +269,9 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, 
     // conditions in the single branch below; the stages computed meanwhile are simply discarded
     const bool fail = it.h_abs < it.min_step || it.attempts >= RK_MAX_ATTEMPTS;
     const double t = it.t, y = it.y, negVmax = it.negVmax, Km = it.Km;
-    double t_new = t + it.h_abs;
-    if (t_new - it.t_bound > 0) t_new = it.t_bound;
+    // rk.py:137-141: t_new = t + h_abs, clipped to t_bound - a minimum (v_min_f64 instead of a compare and two selects; h_abs is
+    // never NaN for finite parameters: the controller's factors come out of Python's min / max, which drop a NaN)
+    const double t_new = fmin(t + it.h_abs, it.t_bound);
     const double h = t_new - t;
     it.h_abs = fabs(h);
 
@@ -251,13 +281,12 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, 
 
     // 0.9 * error_norm ** -0.2 is needed by both branches of rk.py:149-171 (error_norm == 0 gives inf,
     // which min(MAX_FACTOR, .) turns into MAX_FACTOR exactly as the reference's special case does).
-    // Accept / reject is written with selects, not branches: on the serial chain of a stiff solve every
-    // vector-compare -> scalar-branch round trip costs as much as several FP64 operations.  The one
-    // branch below covers both the rare IEEE re-run and the dense output.
+    // Accept / reject is written with selects, not branches: with per-lane operands every vector-compare ->
+    // exec-mask round trip costs as much as several FP64 operations.  The one branch below covers both the rare IEEE re-run
+    // and the dense output.
     double pw = 0.9 * pow_minus_fifth<EXACT>(st.error_norm);
     bool accept = st.error_norm < 1.0;
-    const bool redo = !EXACT && !(st.error_norm <= 1.7976931348623157e308);   // NaN / inf from the lean division
-    const double t_old = t, y_old = y;
+    const bool redo = !EXACT && !__builtin_isfinite(st.error_norm);   // NaN / inf from the lean division (v_cmp_class: no constant)
     if (fail || redo || (accept && it.t_next <= t_new)) {
         if (fail) return 2;
         if (redo) {
@@ -265,33 +294,8 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, 
             pw = 0.9 * pow_minus_fifth<EXACT>(st.error_norm);
             accept = st.error_norm < 1.0;
         }
-        if (accept && it.t_next <= t_new) {
-            // ---- outputs with t_eval in (t_old, t] (ivp.py:700-720) by the quartic interpolant ----
-            const double k1 = st.k1, k2 = st.k2, k3 = st.k3, k4 = st.k4, k5 = st.k5, k6 = st.k6;
-            (void)k1;
-        // Q = K.T.dot(P) (rk.py:179); P[1][:] = 0 and P[j][0] = 0 for j > 0
-        const double Q0 = k0;
-        const double Q1 = k0 * (-8048581381.0 / 2820520608) + k2 * (131558114200.0 / 32700410799) +
-                          k3 * (-1754552775.0 / 470086768) + k4 * (127303824393.0 / 49829197408) +
-                          k5 * (-282668133.0 / 205662961) + k6 * (40617522.0 / 29380423);
-        const double Q2 = k0 * (8663915743.0 / 2820520608) + k2 * (-68118460800.0 / 10900136933) +
-                          k3 * (14199869525.0 / 1410260304) + k4 * (-318862633887.0 / 49829197408) +
-                          k5 * (2019193451.0 / 616988883) + k6 * (-110615467.0 / 29380423);
-        const double Q3 = k0 * (-12715105075.0 / 11282082432) + k2 * (87487479700.0 / 32700410799) +
-                          k3 * (-10690763975.0 / 1880347072) + k4 * (701980252875.0 / 199316789632) +
-                          k5 * (-1453857185.0 / 822651844) + k6 * (69997945.0 / 29380423);
-        const double hd = t_new - t_old;  // RkDenseOutput.__init__ (rk.py:555)
-        // x = (t_eval - t_old) / h (rk.py:566) by the six-operation division when its operands are safely inside the
-        // normal range: h itself, and the numerator, which is either 0 (t_eval == t_old, first step only), or t_eval
-        // (t_old == 0: smc_set_model_mm admits only data times that are 0 or >= 2^-400 in magnitude), or at least one
-        // ulp of |t_old| >= 2^-400.  Two copies of the loop rather than a select per output.
-        const bool lean_x = (DIV != kDivIeee) && hd >= 0x1p-400 && hd <= 0x1p400 &&
-                            (t_old == 0.0 || fabs(t_old) >= 0x1p-400);
-        if (lean_x)
-            mm_dense_outputs<WRITE_PRED, true>(it, s_tp, t_old, t_new, hd, y_old, Q0, Q1, Q2, Q3, pred);
-        else
-            mm_dense_outputs<WRITE_PRED, false>(it, s_tp, t_old, t_new, hd, y_old, Q0, Q1, Q2, Q3, pred);
-        }
+        // ---- outputs with t_eval in (t_old, t] (ivp.py:700-720) by the quartic interpolant ----
+        if (accept && it.t_next <= t_new) mm_attempt_outputs<WRITE_PRED, DIV>(it, s_tp, st, k0, t, t_new, y, pred);
     }
     double fac_acc = py_min(10.0, pw);
     fac_acc = it.rejected ? py_min(1.0, fac_acc) : fac_acc;
@@ -307,5 +311,13 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, 
     it.h_abs = (accept && it.h_abs < it.min_step) ? it.min_step : it.h_abs;
     return (accept && (t_new - it.t_bound >= 0)) ? 1 : 0;  // base.py:196
 }
+
+// Tried for the lone chain of the uniform tail and NOT adopted (round 3, tools/isa_blocks.py on the listings): (a) a twin
+// of this function with rk.py's own branches instead of the selects - bit-identical, 14 selects fewer, but inside the
+// scheduler the compiler then re-materialises 25 instead of 5 FP64 constants per attempt (51 s_mov_b32: 223 instructions per
+// attempt instead of 190); (b) the same as a real function call (own register allocation): the call's register needs drive
+// the whole kernel to 149 VGPRs = 3 waves per SIMD (and hipcc 7.2 fails on an LDS pointer passed through the call); (c) the
+// Dormand-Prince tableau pinned in vector registers by opaque v_mov (the lone wave has registers to spare): 177 VGPRs
+// kernel-wide, or 55 spills under a 128-register cap, and the IEEE re-run gets if-converted into the loop body.
 
 }  // namespace smc
