@@ -1196,3 +1196,34 @@ def test_fused_ess_search_equals_max_plus_partials(pkg, data, n_cand):
     assert np.array_equal(sw_again, sw[:3])
     w = np.exp((lk - lk.max())[None, :] * gms[:, None])
     assert np.allclose(sw, w.sum(axis=1), rtol=1e-12) and np.allclose(sw2, (w * w).sum(axis=1), rtol=1e-12)
+
+
+def test_in_phase_waves_change_no_result(pkg, data):
+    """smc_set_in_phase: homogeneous Metropolis sweeps let a wave wait for all of its lanes before the next hand-out
+    (csrc/solve_sched.h: patience).  Scheduling only: four fused iterations on a posterior-like population (the second and
+    later ones qualify: the previous sweep had no long item) and a complete run are bit-identical with the feature on and off."""
+    n = 150_000
+    s = pkg.SMCSettings(n_particle=n)
+    w_cov = s.w_cov()
+    rs = np.random.RandomState(31)
+    th = np.array([1.2254, 0.5218, 0.02048]) + rs.standard_normal((n, 3)) * np.array([0.025, 0.0295, 0.00094])
+    res = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            eng.set_in_phase(on)
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            eng.loglik(pkg.SMC_SET_PRED)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+            outs = [eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 9, (2 << 16) | j, 0) for j in range(4)]
+            res[on] = ([(o["accepted_now"], o["rk_attempts"]) for o in outs], eng.download_particles(pkg.SMC_SET_FILT),
+                       eng.download_lk(pkg.SMC_SET_FILT))
+    assert res[True][0] == res[False][0]
+    assert np.array_equal(res[True][1], res[False][1]) and np.array_equal(res[True][2], res[False][2])
+    runs = {}
+    for on in (True, False):
+        with make_engine(pkg, data, 100_000) as eng:
+            runs[on] = pkg.run_smc(eng, pkg.SMCSettings(n_particle=100_000, in_phase=on), rng="device", verbose=False, seed_device=29)
+    a, b = runs[True], runs[False]
+    assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
