@@ -1216,7 +1216,7 @@ def test_in_phase_waves_change_no_result(pkg, data):
             eng.upload_particles(pkg.SMC_SET_FILT, th)
             eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
             outs = [eng.mh_iteration_device_rng(1.0, 1.0, w_cov, 9, (2 << 16) | j, 0) for j in range(4)]
-            res[on] = ([(o["accepted_now"], o["rk_attempts"]) for o in outs], eng.download_particles(pkg.SMC_SET_FILT),
+            res[on] = ([o["accepted_now"] for o in outs], eng.download_particles(pkg.SMC_SET_FILT),     # (rk_attempts depends on timing: early rejection)
                        eng.download_lk(pkg.SMC_SET_FILT))
     assert res[True][0] == res[False][0]
     assert np.array_equal(res[True][1], res[False][1]) and np.array_equal(res[True][2], res[False][2])
