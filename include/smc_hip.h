@@ -143,10 +143,13 @@ int smc_set_prior_mode(smc_ctx *ctx, int mode);
  * they are proposals with Vmax/Km in the thousands whose other experiments already rule them out. */
 int smc_set_early_reject(smc_ctx *ctx, int enable);
 /* Michaelis-Menten sweeps hand the predictably long solves (Vmax > 60 Km: RK45 runs on its stability limit for ~3.7 Vmax/Km
- * attempts) out BEFORE the index-ordered items (default: on), so that the serial chain that bounds a sweep starts at its
- * beginning.  The order in which independent (particle, experiment) solves run changes no result - the reference's
- * one-Ray-task-per-particle fan-out (Micmem_likelihood.py:83-87) leaves it to its scheduler too; 0 restores round 2's
- * plain index order (A/B timing, tests). */
+ * attempts) out BEFORE the index-ordered items (default: on), so that the serial chains that bound a sweep start at its
+ * beginning, and run the stiffest of them (Vmax > 1000 Km, at most 2048 particles per sweep) SOLO: one wave per solve on
+ * wave-uniform operands from the first attempt (0.43 instead of ~0.55 us per attempt while the rest of the population
+ * keeps the other lanes busy).  The order in which independent (particle, experiment) solves run - and the lane count they
+ * run on - changes no result: the reference's one-Ray-task-per-particle fan-out (Micmem_likelihood.py:83-87) leaves it to its
+ * scheduler too; 0 restores round 2's plain index order (A/B timing, tests).  Methanation: the same switch selects the
+ * misfit order of the experiments in the early-rejection sweeps (smc_meth_sweep_check). */
 int smc_set_stiff_first(smc_ctx *ctx, int enable);
 /* Michaelis-Menten Metropolis sweeps over a homogeneous population (the previous sweep of the context had fewer than one
  * (particle, experiment) solve in 20 000 with more than 64 RK45 attempts - counted on the device) run their waves IN PHASE

@@ -63,18 +63,39 @@ constexpr double kSumCancelled = -1.0;
 #define SMC_STIFF_RATIO 60.0
 #endif
 constexpr double kStiffRatio = SMC_STIFF_RATIO;
+// ... and the stiffest of them run SOLO (solve_sched.h): one wave per solve on wave-uniform operands from the first attempt
+// on.  Sharing a wave with 63 other live lanes a chain advances at ~0.55 us per attempt, alone at 0.43; the sweeps of a run
+// are bounded by exactly such chains (3 000 attempts in mid-run, 10^4 in the first Metropolis sweeps, 10^5 in the initial
+// sweep), so the ~1.3 ms the rest of the population keeps the queue busy cost every one of them ~25 % of that stretch.
+// A solo solve wastes 63 lanes, hence only above a second threshold of the same ratio (profiles/r03_ab_solo.log).
+#ifndef SMC_SOLO_RATIO
+#define SMC_SOLO_RATIO 1000.0
+#endif
+constexpr double kSoloRatio = SMC_SOLO_RATIO;
+static_assert(kSoloRatio >= kStiffRatio, "the index-ordered pass skips what either list holds by the stiff predicate alone");
 __device__ __forceinline__ bool mm_is_stiff(double Vmax, double Km) { return Km > 0.0 && Vmax > kStiffRatio * Km; }
+__device__ __forceinline__ bool mm_is_solo(double Vmax, double Km) { return Km > 0.0 && Vmax > kSoloRatio * Km; }
 // One atomic per stiff lane on purpose: no cross-lane read follows it, so it is correct whether or not the compiler's
-// atomic optimiser folds the wave's atomics into one.  Every particle is appended at most once: the list cannot overflow.
-__device__ __forceinline__ void stiff_list_append(const StiffList &sl, int64_t p) {
-    const unsigned idx = atomicAdd(sl.count, 1u);
-    sl.particles[idx] = (int32_t)p;
+// atomic optimiser folds the wave's atomics into one.  Every particle is appended at most once, to one of the two lists,
+// which grow towards each other in one array of n entries: they cannot overflow.
+// The solo list is capped (a population of nothing but very stiff particles must not turn every solve into a one-lane
+// wave): a particle that finds it full goes onto the ordinary list; the solve kernel reads min(count[1], kSoloCap).
+constexpr unsigned kSoloCap = 2048;     // particles: x n_ex items = three rounds over the 4 096 waves of the persistent grid
+__device__ __forceinline__ void stiff_list_append(const StiffList &sl, int64_t p, double Vmax, double Km) {
+    if (mm_is_solo(Vmax, Km)) {
+        const unsigned k = atomicAdd(sl.count + 1, 1u);
+        if (k < kSoloCap) {
+            sl.particles[sl.cap - 1 - (int64_t)k] = (int32_t)p;
+            return;
+        }
+    }
+    sl.particles[atomicAdd(sl.count, 1u)] = (int32_t)p;
 }
 __global__ void __launch_bounds__(256)
 mm_stiff_scan_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, StiffList sl) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *sl.count_next = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 2) sl.count_next[threadIdx.x] = 0u;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n && mm_is_stiff(theta[p], theta[stride + p])) stiff_list_append(sl, p);
+    if (p < n && mm_is_stiff(theta[p], theta[stride + p])) stiff_list_append(sl, p, theta[p], theta[stride + p]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -87,7 +108,7 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
         if (mh.zero_counters && threadIdx.x < sizeof(SweepCounters) / 8)
             reinterpret_cast<unsigned long long *>(mh.zero_counters)[threadIdx.x] = 0ull;
         if (mh.zero_queue && threadIdx.x == 64) mh.zero_queue[0] = 0ull;
-        if (mh.stiff.particles && threadIdx.x == 65) *mh.stiff.count_next = 0u;
+        if (mh.stiff.particles && (threadIdx.x == 65 || threadIdx.x == 67)) mh.stiff.count_next[threadIdx.x == 67] = 0u;
         if (mh.reject_out && threadIdx.x == 66) {   // what mm_certainly_rejected reads during the solve of this sweep
             RejectArgs r;
             r.lk1 = mh.reject_lk1;
@@ -150,7 +171,7 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
     p0_out[p] = (uint8_t)(p0 != 0.0);
     // a proposal inside the support whose solves will be long: onto the list of this sweep (the solve kernel applies the
     // same predicate to the same stored values when it skips the particle in its index-ordered pass)
-    if (mh.stiff.particles && p0 != 0.0 && mm_is_stiff(w0, w1)) stiff_list_append(mh.stiff, p);
+    if (mh.stiff.particles && p0 != 0.0 && mm_is_stiff(w0, w1)) stiff_list_append(mh.stiff, p, w0, w1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -173,8 +194,9 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     double *pred;               // optional: P_model, [(p*n_ex + e)*n_t + i]
     unsigned long long *queue;  // global item counter (zeroed before the launch)
     const RejectArgs *rej;      // exact early rejection (Metropolis sweeps only; nullptr: off): see mm_certainly_rejected()
-    const int32_t *stiff_list;  // particles whose solves are handed out first (nullptr: none), and how many
-    const unsigned *stiff_count;
+    const int32_t *stiff_list;  // particles whose solves are handed out first (nullptr: none), and how many: [0] in the
+    const unsigned *stiff_count;    // list proper (from the front of the array), [1] solo (from its back, stiff_cap - 1 downwards)
+    int64_t stiff_cap;
     int patience;               // solve_sched.h: attempts a wave waits for all its lanes before a hand-out (homogeneous sweeps)
 };
 
@@ -254,6 +276,8 @@ struct MMOps {
     int n_ex, n_t;
     const int32_t *list;
     unsigned n_list;
+    const int32_t *solo;        // n_solo particles at solo[0], solo[-1], ... (the back of the list array)
+    unsigned n_solo;
     double rtol, atol;
     int patience;
 
@@ -374,8 +398,11 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     __syncthreads();
     // the wave's pool of STARTED items (solve_sched.h): a ring of 64 slots of kPoolWords words
     double *s_pool = s_S0 + ((n_ex + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kPoolWords * kWave);
-    const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)*a.stiff_count) : 0u;
-    MMOps<WRITE_PRED, EXACT> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff, mm.rtol, mm.atol, a.patience};
+    const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[0]) : 0u;
+    unsigned n_solo = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[1]) : 0u;
+    if (n_solo > kSoloCap) n_solo = kSoloCap;       // the overflow went onto the ordinary list (stiff_list_append)
+    MMOps<WRITE_PRED, EXACT> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff,
+                                 a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, mm.rtol, mm.atol, a.patience};
     solve_persistent(ops, a.queue, s_pool);
 }
 
@@ -529,8 +556,9 @@ static StiffList next_stiff_list(smc_ctx *ctx) {
     if (!ctx->stiff_first || !ctx->d_stiff_list) return sl;
     ctx->stiff_parity ^= 1;
     sl.particles = ctx->d_stiff_list;
-    sl.count = ctx->d_stiff_count + ctx->stiff_parity;
-    sl.count_next = ctx->d_stiff_count + (ctx->stiff_parity ^ 1);
+    sl.count = ctx->d_stiff_count + 2 * ctx->stiff_parity;
+    sl.count_next = ctx->d_stiff_count + 2 * (ctx->stiff_parity ^ 1);
+    sl.cap = ctx->item_cap;
     return sl;
 }
 
@@ -549,6 +577,7 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.rej = reject ? ctx->d_reject : nullptr;
     a.stiff_list = sl.particles;
     a.stiff_count = sl.count;
+    a.stiff_cap = sl.cap;
     a.patience = patience;
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);

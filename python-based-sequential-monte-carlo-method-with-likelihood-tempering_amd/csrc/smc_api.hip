@@ -138,8 +138,8 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->d_counters, sizeof(SweepCounters)));
     CK(hipMalloc(&c->d_queue, 2 * sizeof(unsigned long long)));
     CK(hipMalloc(&c->d_reject, sizeof(RejectArgs)));
-    CK(hipMalloc(&c->d_stiff_count, 2 * sizeof(unsigned)));
-    CK(hipMemsetAsync(c->d_stiff_count, 0, 2 * sizeof(unsigned), c->stream));
+    CK(hipMalloc(&c->d_stiff_count, 4 * sizeof(unsigned)));
+    CK(hipMemsetAsync(c->d_stiff_count, 0, 4 * sizeof(unsigned), c->stream));
     CK(hipMalloc(&c->d_p0, (size_t)n_local));
     {
         hipDeviceProp_t prop;
@@ -510,7 +510,7 @@ static int ensure_item_capacity(smc_ctx *c, int64_t n) {
     HIPC(c, hipMalloc(&c->d_sum_r2, (size_t)n * c->mm.n_ex * sizeof(double)));
     HIPC(c, hipMalloc(&c->d_info, (size_t)n * c->mm.n_ex * sizeof(int)));
     HIPC(c, hipMalloc(&c->d_stiff_list, (size_t)n * sizeof(int32_t)));   // every particle at most once per sweep
-    HIPC(c, hipMemsetAsync(c->d_stiff_count, 0, 2 * sizeof(unsigned), c->stream));
+    HIPC(c, hipMemsetAsync(c->d_stiff_count, 0, 4 * sizeof(unsigned), c->stream));
     c->item_cap = n;
     return 0;
 }

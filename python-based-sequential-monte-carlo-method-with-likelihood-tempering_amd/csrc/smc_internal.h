@@ -58,9 +58,10 @@ struct SweepCounters;
 // the index-ordered items so that the serial chains that bound a sweep start at its very beginning.  Two counters used
 // alternately: the kernel that builds the list of sweep k clears the counter of sweep k + 1.
 struct StiffList {
-    int32_t *particles;         // capacity = item_cap (every particle at most once per sweep)
-    unsigned *count;            // the counter of THIS sweep
-    unsigned *count_next;       // the other one: cleared while this sweep's list is built
+    int32_t *particles;         // capacity = item_cap: the stiff list grows from the front, the solo list from the back
+    unsigned *count;            // [0] stiff entries, [1] solo entries of THIS sweep
+    unsigned *count_next;       // the other pair: cleared while this sweep's lists are built
+    int64_t cap;                // entries in `particles`
 };
 
 struct MHParams {    // passed by value to the fused MH kernel

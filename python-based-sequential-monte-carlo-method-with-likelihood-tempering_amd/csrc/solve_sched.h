@@ -26,6 +26,8 @@
 //   static constexpr int kPoolWords      8-byte words pack() writes
 //   long long n; int n_ex;               particles, experiments; item order (e * n_blk64 + blk) * 64 + lane (experiment-major)
 //   const int *list; unsigned n_list;    particles handed out first, or nullptr / 0
+//   const int *solo; unsigned n_solo;    particles solo[0], solo[-1], ... whose solves run one per wave on uniform operands
+//                                        from their first attempt on (the stiffest of the list), or nullptr / 0
 //   int start(long long p, int e, bool from_list, Item &nb)
 //                                        kStartStarted: nb needs attempts; kStartDone: the item is finished and published
 //                                        (nothing to integrate, masked proposal, ...); kStartSkipped: index-ordered pass met a
@@ -99,6 +101,42 @@ __device__ __forceinline__ long long lane_value_ll(long long v, int src) {
                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src));
 }
 
+// One item whose state is the same in every lane (wave-uniform), to the end: attempts in a tight loop of scalar branches,
+// and - in a Metropolis sweep - a look at the exact rejection bound before the first attempt and every kRejectCheckEvery.
+template <class Ops>
+__device__ __forceinline__ void run_item_uniform(Ops &ops, typename Ops::Item &u, bool reject) {
+    // The look at the bound sits in an outer loop so that the attempt loop itself stays the bare serial chain: with the
+    // check inside it the compiler kept the check's operands live across every attempt and reloaded spilled SGPRs in the
+    // loop (0.51 instead of 0.41 us per attempt, tools/tail_latency.py).
+    int st = 0;
+    bool cancelled = false;
+    for (;;) {
+        // Every lane evaluates the same bound on the same operands, but its atomic loads are a source of divergence for
+        // the compiler: without the v_readfirstlane it wraps the WHOLE attempt loop below in exec-mask control flow
+        // (s_and_saveexec per branch, per-lane selects) instead of scalar branches - that is how the uniform tail lost a
+        // tenth of a microsecond per attempt when early rejection went in (tools/isa_blocks.py on the listing: 11
+        // saveexec / 0 s_cbranch_vcc with the bare call, 0 / 8 with the broadcast).
+        if (reject && __builtin_amdgcn_readfirstlane((int)ops.certainly_rejected(u))) {
+            cancelled = true;
+            break;
+        }
+        int budget = kRejectCheckEvery;
+        do {
+            SMC_ISA_MARK("uniform_tail_attempt");
+            st = ops.attempt(u);
+        } while (st == 0 && --budget > 0);
+        if (st != 0) break;
+    }
+    // Every lane holds the same result and stores it to the same address: one wave-wide store of 64 identical values
+    // instead of an `if (lane == src)` - a divergent branch whose join would be the enclosing loop's exit block, which is
+    // exactly what makes the compiler's uniformity analysis call that whole loop, with its ballots and v_readlanes, a cycle
+    // with a divergent exit.
+    if (cancelled)
+        ops.cancel(u);
+    else
+        ops.finish(u, st);
+}
+
 // s_pool: this wave's kPoolWords * 64 doubles of LDS.  queue: the global item counter, zero at launch.
 template <class Ops>
 __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *queue, double *s_pool) {
@@ -114,6 +152,22 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
     const unsigned long long q_list_end = (unsigned long long)list_cpe * n_ex * kChunk;
     const unsigned long long n_items = q_list_end + n_blk * kWave * n_ex;
     const int lane = threadIdx.x & (kWave - 1);
+
+    // ---- solo phase: the stiffest solves of the sweep, one per wave, on wave-uniform operands from their first attempt.
+    // Static round-robin over the waves of the grid (no atomic): item s = e * n_solo + j is experiment e of solo[-j].
+    {
+        const unsigned n_solo = ops.n_solo;
+        const unsigned n_solo_items = n_solo * (unsigned)n_ex;
+        const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+        const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+        const bool reject = ops.reject_enabled();
+        for (unsigned s = wave_id; s < n_solo_items; s += n_waves) {
+            const int e = (int)(s / n_solo);
+            const long long p = ops.solo[-(long long)(s - (unsigned)e * n_solo)];
+            Item u;
+            if (ops.start(p, e, true, u) == kStartStarted) run_item_uniform(ops, u, reject);   // every lane: the same item
+        }
+    }
 
     Item it;
     bool live = false;              // this lane holds a running item
@@ -229,37 +283,7 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
                 if (n_live == 1) {
                     const int src = __ffsll((unsigned long long)tail_mask) - 1;
                     Item u = ops.broadcast(it, src);
-                    // The look at the bound sits in an outer loop so that the attempt loop itself stays the bare serial
-                    // chain: with the check inside it the compiler kept the check's operands live across every attempt
-                    // and reloaded spilled SGPRs in the loop (0.51 instead of 0.41 us per attempt, tools/tail_latency.py).
-                    int st = 0;
-                    bool cancelled = false;
-                    for (;;) {
-                        // first look at once.  Every lane evaluates the same bound on the same operands, but its atomic
-                        // loads are a source of divergence for the compiler: without the v_readfirstlane it wraps the
-                        // WHOLE attempt loop below in exec-mask control flow (s_and_saveexec per branch, per-lane selects)
-                        // instead of scalar branches - that is how the uniform tail lost a tenth of a microsecond per
-                        // attempt when early rejection went in (tools/isa_blocks.py on the listing: 11 saveexec / 0
-                        // s_cbranch_vcc with the bare call, 0 / 8 with the broadcast).
-                        if (reject && __builtin_amdgcn_readfirstlane((int)ops.certainly_rejected(u))) {
-                            cancelled = true;
-                            break;
-                        }
-                        int budget = kRejectCheckEvery;
-                        do {
-                            SMC_ISA_MARK("uniform_tail_attempt");
-                            st = ops.attempt(u);
-                        } while (st == 0 && --budget > 0);
-                        if (st != 0) break;
-                    }
-                    // Every lane holds the same result and stores it to the same address: one wave-wide store of 64
-                    // identical values instead of an `if (lane == src)` - a divergent branch whose join would be this
-                    // loop's exit block, which is exactly what makes the compiler's uniformity analysis call the whole tail
-                    // loop, with its ballots and v_readlanes, a cycle with a divergent exit.
-                    if (cancelled)
-                        ops.cancel(u);
-                    else
-                        ops.finish(u, st);
+                    run_item_uniform(ops, u, reject);
                     live = false;
                     break;
                 }

@@ -241,6 +241,8 @@ struct UserOps {
     int n_ex;
     const int *list;            // no list of predictably long items for a model the library knows nothing about
     unsigned n_list;
+    const int *solo;            // ... and no solo solves
+    unsigned n_solo;
     int patience;               // in-phase waves (solve_sched.h): not used for user models
 
     __device__ __forceinline__ const double *cond(int e) const { return a.cond + (long long)e * a.n_cond; }
@@ -383,7 +385,7 @@ extern "C" __global__ void __launch_bounds__(256) smc_user_solve_kernel(smc::Use
         s_obs[i] = a.obs[i];
     }
     __syncthreads();
-    UserOps ops{a, a.n, a.n_ex, nullptr, 0u, 0, s_t, s_obs};
+    UserOps ops{a, a.n, a.n_ex, nullptr, 0u, nullptr, 0u, 0, s_t, s_obs};
     smc::solve_persistent(ops, a.queue, s_pool);
 }
 )SRC";
