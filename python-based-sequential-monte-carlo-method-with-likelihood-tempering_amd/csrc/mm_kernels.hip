@@ -78,13 +78,14 @@ __device__ __forceinline__ bool mm_is_solo(double Vmax, double Km) { return Km >
 // One atomic per stiff lane on purpose: no cross-lane read follows it, so it is correct whether or not the compiler's
 // atomic optimiser folds the wave's atomics into one.  Every particle is appended at most once, to one of the two lists,
 // which grow towards each other in one array of n entries: they cannot overflow.
-// The solo list is capped (a population of nothing but very stiff particles must not turn every solve into a one-lane
-// wave): a particle that finds it full goes onto the ordinary list; the solve kernel reads min(count[1], kSoloCap).
-constexpr unsigned kSoloCap = 2048;     // particles: x n_ex items = three rounds over the 4 096 waves of the persistent grid
+// The solo list is capped at what the grid of the sweep can run at once - one solo solve per wave (sl.solo_cap particles x
+// n_ex experiments <= waves; a population of nothing but very stiff particles must not turn every solve into a one-lane
+// wave, and a small grid must not queue solo solves behind each other): a particle that finds it full goes onto the
+// ordinary list; the solve kernel reads min(count[1], solo_cap).
 __device__ __forceinline__ void stiff_list_append(const StiffList &sl, int64_t p, double Vmax, double Km) {
     if (mm_is_solo(Vmax, Km)) {
         const unsigned k = atomicAdd(sl.count + 1, 1u);
-        if (k < kSoloCap) {
+        if (k < sl.solo_cap) {
             sl.particles[sl.cap - 1 - (int64_t)k] = (int32_t)p;
             return;
         }
@@ -197,6 +198,7 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     const int32_t *stiff_list;  // particles whose solves are handed out first (nullptr: none), and how many: [0] in the
     const unsigned *stiff_count;    // list proper (from the front of the array), [1] solo (from its back, stiff_cap - 1 downwards)
     int64_t stiff_cap;
+    unsigned solo_cap;
     int patience;               // solve_sched.h: attempts a wave waits for all its lanes before a hand-out (homogeneous sweeps)
 };
 
@@ -400,7 +402,7 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     double *s_pool = s_S0 + ((n_ex + 1) & ~1) + (size_t)(threadIdx.x >> 6) * (kPoolWords * kWave);
     const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[0]) : 0u;
     unsigned n_solo = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[1]) : 0u;
-    if (n_solo > kSoloCap) n_solo = kSoloCap;       // the overflow went onto the ordinary list (stiff_list_append)
+    if (n_solo > a.solo_cap) n_solo = a.solo_cap;   // the overflow went onto the ordinary list (stiff_list_append)
     MMOps<WRITE_PRED, EXACT> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff,
                                  a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, mm.rtol, mm.atol, a.patience};
     solve_persistent(ops, a.queue, s_pool);
@@ -550,8 +552,21 @@ static size_t solve_lds_bytes(int n_ex, int n_t) {
            (size_t)(kSolveBlock / kWave) * kPoolWords * kWave * sizeof(double);
 }
 
-// The stiff list of the next sweep: its counter, and the other one for the kernel that builds the list to clear.
-static StiffList next_stiff_list(smc_ctx *ctx) {
+// Persistent grid of a sweep over n particles: enough blocks to fill every CU at the kernel's occupancy; for a small
+// population as many as its chunks need plus one wave per item, so that every solo solve finds a wave of its own (blocks
+// beyond the work find the queue empty and leave at once).
+static int64_t solve_grid_blocks(const smc_ctx *ctx, int64_t n) {
+    const int64_t waves_per_block = kSolveBlock / kWave;
+    const int64_t items = ((n + kWave - 1) / kWave) * kWave * ctx->mm.n_ex;
+    const int64_t chunks = (items + kChunk - 1) / kChunk;
+    const int64_t need = (chunks + waves_per_block - 1) / waves_per_block + (n * ctx->mm.n_ex + waves_per_block - 1) / waves_per_block;
+    int64_t blocks = (int64_t)ctx->cu_count * ctx->solve_blocks_per_cu;
+    if (blocks > need) blocks = need;
+    return blocks < 1 ? 1 : blocks;
+}
+
+// The lists of the next sweep: their counters, and the other pair for the kernel that builds the lists to clear.
+static StiffList next_stiff_list(smc_ctx *ctx, int64_t n) {
     StiffList sl{};
     if (!ctx->stiff_first || !ctx->d_stiff_list) return sl;
     ctx->stiff_parity ^= 1;
@@ -559,6 +574,7 @@ static StiffList next_stiff_list(smc_ctx *ctx) {
     sl.count = ctx->d_stiff_count + 2 * ctx->stiff_parity;
     sl.count_next = ctx->d_stiff_count + 2 * (ctx->stiff_parity ^ 1);
     sl.cap = ctx->item_cap;
+    sl.solo_cap = (unsigned)(solve_grid_blocks(ctx, n) * (kSolveBlock / kWave) / ctx->mm.n_ex);   // one solo solve per wave
     return sl;
 }
 
@@ -578,6 +594,7 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.stiff_list = sl.particles;
     a.stiff_count = sl.count;
     a.stiff_cap = sl.cap;
+    a.solo_cap = sl.solo_cap;
     a.patience = patience;
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
@@ -598,20 +615,14 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
         }
         ctx->solve_lds_raised = true;
     }
-    // persistent grid: enough blocks to fill every CU at the kernel's occupancy, never more blocks than chunks (the chunks
-    // of the stiff list are extra; how many is only known on the device, the waves simply go on until the queue is empty)
-    const int64_t chunks = (((n + kWave - 1) / kWave) * kWave * mm.n_ex + kChunk - 1) / kChunk;
-    int64_t blocks = (int64_t)ctx->cu_count * ctx->solve_blocks_per_cu;
-    const int64_t need = (chunks + (kSolveBlock / kWave) - 1) / (kSolveBlock / kWave);
-    if (blocks > need) blocks = need;
-    if (blocks < 1) blocks = 1;
+    const int64_t blocks = solve_grid_blocks(ctx, n);   // the waves go on until the queue is empty
     ScopedTimer tm(ctx, SMC_T_SOLVE);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSolveBlock), lds, ctx->stream, mm, a);
 }
 
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred) {
     if (n <= 0) return;
-    const StiffList sl = next_stiff_list(ctx);
+    const StiffList sl = next_stiff_list(ctx, n);
     if (sl.particles)
         hipLaunchKernelGGL(mm_stiff_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, theta, stride, n, sl);
     launch_solve(ctx, theta, stride, n, nullptr, pred, sl);
@@ -635,7 +646,7 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
         mh.reject_out = ctx->d_reject;
         mh.reject_lk1 = F.lk;
     }
-    mh.stiff = next_stiff_list(ctx);
+    mh.stiff = next_stiff_list(ctx, n);
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
     // in phase (solve_sched.h) when the previous Metropolis sweep of this context had fewer than 1 long item in 20 000

@@ -62,6 +62,7 @@ struct StiffList {
     unsigned *count;            // [0] stiff entries, [1] solo entries of THIS sweep
     unsigned *count_next;       // the other pair: cleared while this sweep's lists are built
     int64_t cap;                // entries in `particles`
+    unsigned solo_cap;          // solo entries this sweep's grid can run at once (one per wave): the rest join the ordinary list
 };
 
 struct MHParams {    // passed by value to the fused MH kernel

@@ -161,7 +161,7 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
         const unsigned wave_id = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
         const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
         const bool reject = ops.reject_enabled();
-        for (unsigned s = wave_id; s < n_solo_items; s += n_waves) {
+        for (unsigned s = wave_id; s < n_solo_items; s += n_waves) {   // at most one per wave when the caller caps n_solo at waves / n_ex
             const int e = (int)(s / n_solo);
             const long long p = ops.solo[-(long long)(s - (unsigned)e * n_solo)];
             Item u;
