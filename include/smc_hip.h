@@ -91,11 +91,22 @@ int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *gu
  * gfx950) into a kernel that restates solve_ivp(RK45, t_eval = t[e], rtol, atol) and the Gaussian log-likelihood of
  * Micmem_likelihood.py:17-33,62-73 with sigma = the last parameter (est_sigma) or sigma_fixed; smc_loglik and
  * smc_mh_step_* then use it.  t, obs: n_ex x n_t; cond: n_ex x n_cond.  A source that does not compile fails with
- * hiprtc's log in smc_last_error.  smc_user_model_check only compiles (no GPU needed): 0 ok, 1 compile error (log). */
+ * hiprtc's log in smc_last_error.  smc_user_model_check only compiles (no GPU needed): 0 ok, 1 compile error (log).
+ * Optional fourth ingredient, a COST HINT (a source that contains the name must define it):
+ *   __device__ double smc_user_cost(const double *theta);      rough number of RK45 step attempts of one solve with theta
+ * Sweeps then hand the solves of particles above 220 attempts out before the index-ordered ones and run those above 3700
+ * one per wave on wave-uniform operands (the built-in Michaelis-Menten kernel's stiff list and solo phase, smc_set_stiff_first
+ * switches both off) - a sweep over a prior population is bounded by its longest serial solve, which should start first.
+ * The hint changes the order of independent solves only, never a result; it may be crude, and NaN counts as cheap. */
 #define SMC_USER_MAX_STATES 8
 int smc_set_model_user(smc_ctx *ctx, const char *source, int n_states, const double *t, const double *obs, const double *cond,
                        int n_ex, int n_t, int n_cond, int est_sigma, double sigma_fixed, double rtol, double atol);
 int smc_user_model_check(const char *source, int n_states, int dim, char *log, int log_cap);
+/* Writes exactly what hiprtc is given for `source` into the existing directory `dir`: smc_user_model.hip (the user's functions
+ * followed by the library's kernel) and the four headers it includes - to read, or to compile off line
+ * (`hipcc --offload-arch=gfx950 -O3 -ffp-contract=on -fno-fast-math -I dir -S dir/smc_user_model.hip`; the build container's
+ * tests run the compiler's uniformity analysis on it).  0 ok, 1 a file could not be written, 2 bad arguments.  No GPU needed. */
+int smc_user_model_dump_source(const char *source, int n_states, int dim, const char *dir);
 /* Methanation model: device-counted work of the LAST smc_loglik / smc_mh_step_* call (the counts the K8
  * roofline is built from): out = {accepted BDF steps, Newton iterations, Jacobian factorisations, failed solves}. */
 int smc_meth_sweep_counters(smc_ctx *ctx, int64_t out[4]);

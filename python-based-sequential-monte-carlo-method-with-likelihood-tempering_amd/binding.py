@@ -48,6 +48,7 @@ SIGNATURES = {
     "smc_set_model_methanation": (cint, [c_ctx, c_dp, c_dp, c_dp, cint, c_dp, c_ip, cint, f64, f64, f64, f64]),
     "smc_set_model_user": (cint, [c_ctx, ctypes.c_char_p, cint, c_dp, c_dp, c_dp, cint, cint, cint, cint, f64, f64, f64]),
     "smc_user_model_check": (cint, [ctypes.c_char_p, cint, cint, ctypes.c_char_p, cint]),
+    "smc_user_model_dump_source": (cint, [ctypes.c_char_p, cint, cint, ctypes.c_char_p]),
     "smc_meth_sweep_counters": (cint, [c_ctx, c_i64p]),
     "smc_meth_sweep_check": (cint, [c_ctx, c_i64p]),
     "smc_meth_download_solves": (cint, [c_ctx, c_dp, ctypes.POINTER(ctypes.c_int32), i64]),

@@ -47,6 +47,16 @@ __device__ __forceinline__ double lean_div5(double a, double b) {
     const double rem = fma(-b, q1, a);
     return fma(rem, r, q1);
 }
+// a / b for code that cannot re-run itself (user models, user_model.hip: smc_div): the six-operation division, and the
+// compiler's IEEE sequence whenever that did not come out finite (a divisor that is subnormal or whose reciprocal is, an
+// overflowing a * (1 / b), 0 / 0, ...).  Equal to a / b bit for bit unless |b| >= 2^1021 (the reciprocal is subnormal and
+// loses bits) or the quotient itself is subnormal (last bits).  On wave-uniform operands the test is one v_cmp_class and one
+// scalar branch; the IEEE sequence costs ten more instructions and twice the latency on the serial chain of a stiff solve.
+__device__ __forceinline__ double checked_lean_div(double a, double b) {
+    const double q = lean_div6(a, b);
+    if (__builtin_expect(!__builtin_isfinite(q), 0)) return a / b;
+    return q;
+}
 constexpr int kDivIeee = 0, kDivLean6 = 1, kDivLean5 = 2;
 // Python's min(a,b)/max(a,b): keep a unless b is strictly better (NaN never is)
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }

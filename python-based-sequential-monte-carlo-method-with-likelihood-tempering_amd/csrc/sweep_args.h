@@ -30,6 +30,24 @@ struct UserSolveArgs {
     int *info;                  // [e * n + p]: attempts | cancelled << 29 | failed << 30
     unsigned long long *queue;
     const RejectArgs *rej;      // nullptr: no early rejection in this sweep
+    // models with a cost hint (smc_user_cost, include/smc_hip.h): the predictably long solves of the sweep, handed out first
+    const unsigned char *listed;    // [p] != 0: particle p is on one of the two lists (the index-ordered pass skips it)
+    const int *stiff_list;          // nullptr: no lists.  Ordinary list from the front, solo list from the back (stiff_cap - 1 down)
+    const unsigned *stiff_count;    // [0] ordinary, [1] solo entries
+    long long stiff_cap;
+    unsigned solo_cap;              // solo entries the grid runs at once (one per wave); the overflow is on the ordinary list
+};
+
+// Arguments of smc_user_cost_scan_kernel (user_model.hip): builds the two lists and the flags of a sweep from the hint.
+struct UserScanArgs {
+    const double *theta;
+    long long stride, n;
+    const unsigned char *p0;    // masked proposals are not listed
+    unsigned char *listed;
+    int *stiff_list;
+    unsigned *count, *count_next;   // this sweep's pair of counters; the other pair is cleared for the next sweep
+    long long stiff_cap;
+    unsigned solo_cap;
 };
 
 }  // namespace smc

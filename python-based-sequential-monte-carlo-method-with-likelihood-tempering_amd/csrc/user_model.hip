@@ -30,6 +30,21 @@ namespace smc {
 // gets them as in-memory headers, so the run-time compiled kernel is scheduled by the very code the built-in kernel uses
 #include "embedded_headers.inc"
 
+// what the user's functions may call (include/smc_hip.h)
+// The user's functions are compiled TWICE, in two namespaces that differ in what smc_div(a, b) is (include/smc_hip.h): the
+// six-operation division of the built-in kernel, and a / b.  An attempt runs on the first and is repeated on the second
+// whenever its error norm is not finite (smc_user::item_attempt) - the built-in kernel's scheme, for a model it does not know.
+static const char *kUserPreludeLean = R"SRC(
+#include "rk45_math.h"
+namespace smc_user_lean {
+__device__ __forceinline__ double smc_div(double a, double b) { return smc::lean_div6(a, b); }
+)SRC";
+static const char *kUserPreludeIeee = R"SRC(
+}  // namespace smc_user_lean
+namespace smc_user_ieee {
+__device__ __forceinline__ double smc_div(double a, double b) { return a / b; }
+)SRC";
+
 static const char *kUserKernelSource = R"SRC(
 // ---- appended by libsmc_hip.so after the user's source -------------------------------------------------------
 #include "sweep_args.h"     // in-memory headers handed to hiprtc by the library: the argument blocks,
@@ -59,6 +74,17 @@ __device__ const double RK_P[7][4] = {
 
 __device__ __forceinline__ double py_min(double a, double b) { return (b < a) ? b : a; }
 __device__ __forceinline__ double py_max(double a, double b) { return (b > a) ? b : a; }
+// the two compilations of the user's functions (see the prelude): with the six-operation division, and with a / b
+struct Lean {
+    static __device__ __forceinline__ void rhs(double t, const double *y, const double *th, const double *c, double *d) { smc_user_lean::smc_user_rhs(t, y, th, c, d); }
+    static __device__ __forceinline__ double div(double a, double b) { return SMC_USER_USES_DIV ? smc::lean_div6(a, b) : a / b; }
+};
+struct Ieee {
+    static __device__ __forceinline__ void y0(const double *th, const double *c, double *y) { smc_user_ieee::smc_user_y0(th, c, y); }
+    static __device__ __forceinline__ void rhs(double t, const double *y, const double *th, const double *c, double *d) { smc_user_ieee::smc_user_rhs(t, y, th, c, d); }
+    static __device__ __forceinline__ double obs(double t, const double *y, const double *th, const double *c) { return smc_user_ieee::smc_user_obs(t, y, th, c); }
+    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+};
 // common.py:63-65  np.linalg.norm(x) / x.size ** 0.5
 __device__ __forceinline__ double rms(const double *x) {
     if (NS == 1) return fabs(x[0]);   // sqrt(x*x) / sqrt(1) is |x| exactly in IEEE arithmetic (as the built-in kernel writes it)
@@ -73,19 +99,26 @@ __device__ __forceinline__ double rms(const double *x) {
 // when the step is accepted, the t_eval outputs it covers.  sr2 accumulates (obs - smc_user_obs)^2.
 struct Item {
     double t, h_abs, y[NS], f[NS], sr2;
+    double t_bound, t_next;   // t_eval[n_t - 1]; t_eval[i_out] (+inf when every data time has been served) - copies of LDS
+                              // values, so that an attempt without outputs (nearly all of a stiff solve) reads no memory
     int i_out, status;   // status: 0 running, 1 finished, -1 step size underflow (the reference's solver raises)
     bool rejected;
 };
+// The data of one experiment in LDS: n_t + 1 (time, observation) pairs, the last one the sentinel (+inf, 0) - as in the
+// built-in kernel (mm_rk45.h: mm_table_fill), so that an output costs ONE ds_read_b128 and no test for the end of the row.
+__device__ __forceinline__ void item_cache_times(Item &it, const double2 *tp, int n_t) {
+    it.t_bound = tp[n_t - 1].x;
+    it.t_next = tp[it.i_out].x;
+}
 
-__device__ __forceinline__ void emit(Item &it, const double *yy, const double *theta, const double *cond, const double *t_eval,
-                                     const double *obs, int io) {
-    const double r = obs[io] - smc_user_obs(t_eval[io], yy, theta, cond);
+__device__ __forceinline__ void emit(Item &it, const double *yy, const double *theta, const double *cond, double t_out, double obs) {
+    const double r = obs - Ieee::obs(t_out, yy, theta, cond);
     it.sr2 += r * r;
 }
 
-__device__ void item_begin(Item &it, const double *theta, const double *cond, const double *t_eval, const double *obs, int n_t,
+__device__ void item_begin(Item &it, const double *theta, const double *cond, const double2 *tp, int n_t,
                            double rtol, double atol) {
-    const double t0 = t_eval[0], t_bound = t_eval[n_t - 1];
+    const double t0 = tp[0].x, t_bound = tp[n_t - 1].x;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     double tmp[NS];
     it.t = t0;
@@ -93,8 +126,8 @@ __device__ void item_begin(Item &it, const double *theta, const double *cond, co
     it.i_out = 0;
     it.status = 0;
     it.rejected = false;
-    smc_user_y0(theta, cond, it.y);
-    smc_user_rhs(t0, it.y, theta, cond, it.f);
+    Ieee::y0(theta, cond, it.y);
+    Ieee::rhs(t0, it.y, theta, cond, it.f);
     // common.py select_initial_step, direction +1, order 4, max_step inf
     const double interval_length = fabs(t_bound - t0);
     if (interval_length == 0.0) {
@@ -111,7 +144,7 @@ __device__ void item_begin(Item &it, const double *theta, const double *cond, co
         h0 = py_min(h0, interval_length);
 #pragma unroll
         for (int i = 0; i < NS; ++i) y1[i] = it.y[i] + h0 * 1.0 * it.f[i];
-        smc_user_rhs(t0 + h0 * 1.0, y1, theta, cond, f1);
+        Ieee::rhs(t0 + h0 * 1.0, y1, theta, cond, f1);
 #pragma unroll
         for (int i = 0; i < NS; ++i) tmp[i] = (f1[i] - it.f[i]) / scale[i];
         const double d2 = rms(tmp) / h0;
@@ -120,107 +153,139 @@ __device__ void item_begin(Item &it, const double *theta, const double *cond, co
         it.h_abs = py_min(py_min(py_min(100 * h0, h1), interval_length), inf);
     }
     if (it.t == t_bound) {   // base.py:181-187: nothing to integrate
-        while (it.i_out < n_t && t_eval[it.i_out] <= it.t) { emit(it, it.y, theta, cond, t_eval, obs, it.i_out); ++it.i_out; }
+        while (tp[it.i_out].x <= it.t) { emit(it, it.y, theta, cond, tp[it.i_out].x, tp[it.i_out].y); ++it.i_out; }   // stops at the sentinel
         it.status = 1;
     }
+    item_cache_times(it, tp, n_t);
 }
 
-__device__ void item_attempt(Item &it, const double *theta, const double *cond, const double *t_eval, const double *obs,
-                             int n_t, double rtol, double atol) {
-    const double t_bound = t_eval[n_t - 1];
-    const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    const double t = it.t;
-    const double min_step = (t >= 0.0) ? smc::min_step_of(t) : 10 * fabs(nextafter(t, inf) - t);
-    // rk.py:111-121: clip at the start of a step (a value raised here stays raised for the re-tries of the step)
-    if (!it.rejected && it.h_abs < min_step) it.h_abs = min_step;
-    if (it.h_abs < min_step) { it.status = -1; return; }
-    double K[7][NS], y_new[NS], f_new[NS], tmp[NS];
-    double h = it.h_abs;
-    double t_new = t + h;
-    if (t_new - t_bound > 0) t_new = t_bound;
-    h = t_new - t;
-    it.h_abs = fabs(h);
+// rk_step (rk.py:64-71) and the error norm (rk.py:106-110,146-147) of one attempt: a pure function of the item's state.
+// M = the model with smc_div as the six-operation division (Lean) or as the IEEE sequence (Ieee): see item_attempt.
+struct Stages {
+    double K[7][NS], y_new[NS], error_norm;
+};
+template <class M>
+__device__ __forceinline__ void rk_stages(Stages &st, const Item &it, double t, double h, const double *theta, const double *cond,
+                                          double rtol, double atol) {
+    double tmp[NS];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) K[0][i] = it.f[i];
+    for (int i = 0; i < NS; ++i) st.K[0][i] = it.f[i];
 #pragma unroll
     for (int s = 1; s < 6; ++s) {   // rk_step: dy = K[:s].T @ a[:s] * h
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < s; ++j) acc += K[j][i] * RK_A[s][j];
+            for (int j = 0; j < s; ++j) acc += st.K[j][i] * RK_A[s][j];
             tmp[i] = it.y[i] + acc * h;
         }
-        smc_user_rhs(t + RK_C[s] * h, tmp, theta, cond, K[s]);
+        M::rhs(t + RK_C[s] * h, tmp, theta, cond, st.K[s]);
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc += K[j][i] * RK_B[j];
-        y_new[i] = it.y[i] + h * acc;
+        for (int j = 0; j < 6; ++j) acc += st.K[j][i] * RK_B[j];      // b2 = 0 included: 0 * NaN is NaN in NumPy's dot as well
+        st.y_new[i] = it.y[i] + h * acc;
     }
-    smc_user_rhs(t + h, y_new, theta, cond, f_new);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) K[6][i] = f_new[i];
+    M::rhs(t + h, st.y_new, theta, cond, st.K[6]);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        double scale = atol + fmax(fabs(it.y[i]), fabs(y_new[i])) * rtol;
-        if (it.y[i] != it.y[i] || y_new[i] != y_new[i]) scale = it.y[i] + y_new[i];   // np.maximum propagates NaN
+        double scale = atol + fmax(fabs(it.y[i]), fabs(st.y_new[i])) * rtol;
+        if (it.y[i] != it.y[i] || st.y_new[i] != st.y_new[i]) scale = it.y[i] + st.y_new[i];   // np.maximum propagates NaN
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_E[j];
-        tmp[i] = acc * h / scale;
+        for (int j = 0; j < 7; ++j) acc += st.K[j][i] * RK_E[j];
+        tmp[i] = M::div(acc * h, scale);
     }
-    const double error_norm = rms(tmp);
+    st.error_norm = rms(tmp);
+}
+
+// One pass of rk.py's `while not step_accepted` body.  Written like the built-in kernel's mm_item_attempt (mm_rk45.h): the
+// accept / reject bookkeeping as selects, ONE rarely taken branch for everything else (failure, the IEEE re-run, the dense
+// output) - with per-lane operands every compare -> exec-mask round trip costs several FP64 operations, and on the
+// wave-uniform operands of a lone chain every compare -> scalar-branch round trip drains the pipeline.
+// smc_div: the attempt runs on the model compiled with the six-operation division (no scaling, no fix-up: NaN where a / b
+// needs a subnormal or infinite divisor or a * (1 / b) overflows); whenever the error norm does not come out finite the
+// whole attempt is repeated on the model compiled with IEEE division, exactly as the built-in kernel does.
+__device__ __forceinline__ void item_attempt(Item &it, const double *theta, const double *cond, const double2 *tp, double rtol,
+                                             double atol) {
+    const double t_bound = it.t_bound;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    const double t = it.t;
+    const double min_step = (t >= 0.0) ? smc::min_step_of(t) : 10 * fabs(nextafter(t, inf) - t);
+    // rk.py:111-121: clip at the start of a step (a value raised here stays raised for the re-tries of the step)
+    double h_abs = (!it.rejected && it.h_abs < min_step) ? min_step : it.h_abs;
+    const bool fail = h_abs < min_step;                  // rk.py:133-134 TOO_SMALL_STEP: handled in the rare branch below
+    const double t_new = fmin(t + h_abs, t_bound);       // rk.py:137-141 (h_abs is never NaN: Python's min / max drop a NaN factor)
+    const double h = t_new - t;
+    h_abs = fabs(h);
+    Stages st;
+    rk_stages<Lean>(st, it, t, h, theta, cond, rtol, atol);
     // error_norm ** -0.2 (rk.py:155,169) by the dedicated inverse fifth root of the built-in kernel (<= 1.5 ulp; the generic
     // pow costs 350 ns on the dependent chain of an attempt): 0 -> inf, which min(10, .) turns into MAX_FACTOR
-    const double pw = 0.9 * smc::pow_minus_fifth<false>(error_norm);
-    if (!(error_norm < 1)) {   // rejected (also for a NaN norm: Python's max(0.2, nan) is 0.2)
-        it.h_abs *= py_max(0.2, pw);
-        it.rejected = true;
-        return;
-    }
-    double factor = py_min(10.0, pw);
-    if (it.rejected) factor = py_min(1.0, factor);
-    it.h_abs *= factor;
-    it.rejected = false;
-    // outputs in (t, t_new] and t_eval[0] == t0 on the first step (ivp.py:700-720): quartic dense output
-    int i_new = it.i_out;
-    while (i_new < n_t && t_eval[i_new] <= t_new) ++i_new;
-    if (i_new > it.i_out) {
-        double Q[NS][4];
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < 7; ++j) acc += K[j][i] * RK_P[j][k];
-                Q[i][k] = acc;
-            }
-        const double hd = t_new - t;
-        for (int io = it.i_out; io < i_new; ++io) {
-            const double x = (t_eval[io] - t) / hd;
-            const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
-            double yy[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                double acc = 0.0;
-                acc += Q[i][0] * p1;
-                acc += Q[i][1] * p2;
-                acc += Q[i][2] * p3;
-                acc += Q[i][3] * p4;
-                yy[i] = hd * acc + it.y[i];
-            }
-            emit(it, yy, theta, cond, t_eval, obs, io);
+    double pw = 0.9 * smc::pow_minus_fifth<false>(st.error_norm);
+    bool accept = st.error_norm < 1.0;                   // false for a NaN norm: Python's max(0.2, nan) is 0.2
+    const bool redo = SMC_USER_USES_DIV && !__builtin_isfinite(st.error_norm);
+    if (fail || redo || (accept && it.t_next <= t_new)) {
+        if (fail) {
+            it.status = -1;
+            return;
         }
-        it.i_out = i_new;
-    }
-    it.t = t_new;
+        if (redo) {
+            rk_stages<Ieee>(st, it, t, h, theta, cond, rtol, atol);
+            pw = 0.9 * smc::pow_minus_fifth<false>(st.error_norm);
+            accept = st.error_norm < 1.0;
+        }
+        // outputs in (t, t_new] and t_eval[0] == t0 on the first step (ivp.py:700-720): quartic dense output
+        if (accept && it.t_next <= t_new) {
+            double Q[NS][4];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { it.y[i] = y_new[i]; it.f[i] = f_new[i]; }
-    if (t_new - t_bound >= 0) it.status = 1;
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 7; ++j)
+                        if (RK_P[j][k] != 0.0) acc += st.K[j][i] * RK_P[j][k];   // an accepted step has finite K: the zeros change nothing
+                    Q[i][k] = acc;
+                }
+            const double hd = t_new - t;
+            int i_out = it.i_out;
+            double2 nx = tp[i_out];                      // (t_next, its observation)
+            do {
+                const double x = smc::checked_lean_div(nx.x - t, hd);
+                const double p1 = x, p2 = p1 * x, p3 = p2 * x, p4 = p3 * x;
+                double yy[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    double acc = 0.0;
+                    acc += Q[i][0] * p1;
+                    acc += Q[i][1] * p2;
+                    acc += Q[i][2] * p3;
+                    acc += Q[i][3] * p4;
+                    yy[i] = hd * acc + it.y[i];
+                }
+                emit(it, yy, theta, cond, nx.x, nx.y);
+                ++i_out;
+                nx = tp[i_out];                          // i_out == n_t reads the sentinel (+inf, 0)
+            } while (nx.x <= t_new);
+            it.i_out = i_out;
+            it.t_next = nx.x;
+        }
+    }
+    double fac_acc = py_min(10.0, pw);
+    fac_acc = it.rejected ? py_min(1.0, fac_acc) : fac_acc;
+    const double fac_rej = py_max(0.2, pw);
+    it.h_abs = h_abs * (accept ? fac_acc : fac_rej);
+    it.rejected = !accept;
+    it.t = accept ? t_new : t;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        it.y[i] = accept ? st.y_new[i] : it.y[i];
+        it.f[i] = accept ? st.K[6][i] : it.f[i];
+    }
+    it.status = (accept && (t_new - t_bound >= 0)) ? 1 : 0;   // base.py:196
 }
 }  // namespace smc_user
 
@@ -239,16 +304,15 @@ struct UserOps {
     const smc::UserSolveArgs &a;
     long long n;
     int n_ex;
-    const int *list;            // no list of predictably long items for a model the library knows nothing about
-    unsigned n_list;
-    const int *solo;            // ... and no solo solves
+    const int *list;            // the predictably long items of the sweep, handed out first - only for a model that comes with
+    unsigned n_list;            // a cost hint (smc_user_cost; smc_user_cost_scan_kernel below builds the lists), else nullptr / 0
+    const int *solo;            // ... and its longest solves, one per wave on uniform operands
     unsigned n_solo;
     int patience;               // in-phase waves (solve_sched.h): not used for user models
 
     __device__ __forceinline__ const double *cond(int e) const { return a.cond + (long long)e * a.n_cond; }
-    const double *s_t, *s_obs;  // the data times and observations of all experiments, staged in LDS by the kernel
-    __device__ __forceinline__ const double *tt(int e) const { return s_t + e * a.n_t; }
-    __device__ __forceinline__ const double *ob(int e) const { return s_obs + e * a.n_t; }
+    const double2 *s_tp;        // the data of all experiments in LDS: rows of n_t + 1 (time, observation) pairs (item_cache_times)
+    __device__ __forceinline__ const double2 *row(int e) const { return s_tp + e * (a.n_t + 1); }
     __device__ __forceinline__ void publish(long long idx, double sum, int info) const {
         // visible to the waves of other XCDs while the kernel runs (the early-rejection bound reads the siblings' sums)
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.sum_r2) + idx, (unsigned long long)__double_as_longlong(sum),
@@ -259,16 +323,20 @@ struct UserOps {
 #pragma unroll
         for (int c = 0; c < SMC_USER_DIM; ++c) it.th[c] = a.theta[c * a.stride + p];
     }
-    __device__ __forceinline__ int start(long long p, int e, bool, Item &nb) const {
+    __device__ __forceinline__ int start(long long p, int e, bool from_list, Item &nb) const {
         nb.out_idx = (long long)e * a.n + p;
         nb.e = e;
         nb.attempts = 0;
+        // index-ordered pass: a particle of the lists has been handed out already.  The flag was written by the scan kernel
+        // that built the lists - the hint is NOT evaluated a second time here (a user's expression need not round the same
+        // way in two kernels, and an item skipped here but missing from the list would never be solved)
+        if (!from_list && list && a.listed[p] != 0) return smc::kStartSkipped;
         if (a.p0 && a.p0[p] == 0) {          // masked proposal: not solved, the accept kernel keeps lk1
             publish(nb.out_idx, 0.0, 0);
             return smc::kStartDone;
         }
         load_theta(nb, p);
-        smc_user::item_begin(nb.s, nb.th, cond(e), tt(e), ob(e), a.n_t, a.rtol, a.atol);
+        smc_user::item_begin(nb.s, nb.th, cond(e), row(e), a.n_t, a.rtol, a.atol);
         if (nb.s.status == 0) return smc::kStartStarted;
         publish(nb.out_idx, nb.s.sr2, nb.s.status < 0 ? (1 << 30) : 0);
         return smc::kStartDone;
@@ -302,10 +370,11 @@ struct UserOps {
             it.s.y[i] = slot[(6 + i) * 64];
             it.s.f[i] = slot[(6 + NS + i) * 64];
         }
+        smc_user::item_cache_times(it.s, row(it.e), a.n_t);
         load_theta(it, it.out_idx - (long long)it.e * a.n);      // the parameters come from HBM / L2 again, not through the pool
     }
     __device__ __forceinline__ int attempt(Item &it) const {
-        smc_user::item_attempt(it.s, it.th, cond(it.e), tt(it.e), ob(it.e), a.n_t, a.rtol, a.atol);
+        smc_user::item_attempt(it.s, it.th, cond(it.e), row(it.e), a.rtol, a.atol);
         ++it.attempts;
         if (it.attempts >= 0x1fffffffu) it.s.status = -1;        // hard bound so that every wave drains
         return it.s.status;
@@ -318,6 +387,8 @@ struct UserOps {
         u.s.t = smc::lane_value(it.s.t, src);
         u.s.h_abs = smc::lane_value(it.s.h_abs, src);
         u.s.sr2 = smc::lane_value(it.s.sr2, src);
+        u.s.t_bound = smc::lane_value(it.s.t_bound, src);
+        u.s.t_next = smc::lane_value(it.s.t_next, src);
         u.s.i_out = __builtin_amdgcn_readlane(it.s.i_out, src);
         u.s.status = __builtin_amdgcn_readlane(it.s.status, src);
         u.s.rejected = __builtin_amdgcn_readlane((int)it.s.rejected, src) != 0;
@@ -376,18 +447,56 @@ struct UserOps {
 };
 
 // Outputs per item: the sum of squared residuals and attempts | cancelled << 29 | failed << 30.
-extern "C" __global__ void __launch_bounds__(256) smc_user_solve_kernel(smc::UserSolveArgs a) {
+// small models: hold the register allocation at four waves per SIMD (the built-in kernel's occupancy); the re-run with IEEE
+// division would otherwise cost the bulk loop its fourth wave
+#if NS <= 2
+#define SMC_USER_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define SMC_USER_WAVES_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(256) SMC_USER_WAVES_ATTR smc_user_solve_kernel(smc::UserSolveArgs a) {
     extern __shared__ double s_pool_all[];       // per wave: a ring of 64 started items of UserOps::kPoolWords words, then
     double *s_pool = s_pool_all + (threadIdx.x >> 6) * (UserOps::kPoolWords * 64);
-    double *s_t = s_pool_all + 4 * (UserOps::kPoolWords * 64), *s_obs = s_t + a.n_ex * a.n_t;   // the data, read by every output
-    for (int i = threadIdx.x; i < a.n_ex * a.n_t; i += blockDim.x) {
-        s_t[i] = a.t[i];
-        s_obs[i] = a.obs[i];
+    double2 *s_tp = reinterpret_cast<double2 *>(s_pool_all + 4 * (UserOps::kPoolWords * 64));   // the data, read by every output
+    for (int i = threadIdx.x; i < a.n_ex * (a.n_t + 1); i += blockDim.x) {
+        const int e = i / (a.n_t + 1), k = i - e * (a.n_t + 1);
+        s_tp[i] = (k < a.n_t) ? make_double2(a.t[e * a.n_t + k], a.obs[e * a.n_t + k])
+                              : make_double2(__longlong_as_double(0x7ff0000000000000LL), 0.0);
     }
     __syncthreads();
-    UserOps ops{a, a.n, a.n_ex, nullptr, 0u, nullptr, 0u, 0, s_t, s_obs};
+    const unsigned n_list = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[0]) : 0u;
+    unsigned n_solo = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[1]) : 0u;
+    if (n_solo > a.solo_cap) n_solo = a.solo_cap;   // the overflow went onto the ordinary list
+    UserOps ops{a, a.n, a.n_ex, a.stiff_list, n_list, a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, 0, s_tp};
     smc::solve_persistent(ops, a.queue, s_pool);
 }
+
+#ifdef SMC_USER_HAS_COST
+// The cost hint of the model (include/smc_hip.h): smc_user_cost(theta) ~ RK45 step attempts of one solve.  Above
+// SMC_USER_LIST_COST attempts a particle's solves are handed out before the index-ordered items, above SMC_USER_SOLO_COST they
+// run one per wave (solve_sched.h) - the thresholds of the built-in Michaelis-Menten kernel (Vmax > 60 Km, > 1000 Km) in
+// attempts (3.7 Vmax / Km).  One atomic per listed lane, no cross-lane read after it; every particle at most once.
+extern "C" __global__ void __launch_bounds__(256) smc_user_cost_scan_kernel(smc::UserScanArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) a.count_next[threadIdx.x] = 0u;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.n) return;
+    double th[SMC_USER_DIM];
+#pragma unroll
+    for (int c = 0; c < SMC_USER_DIM; ++c) th[c] = a.theta[c * a.stride + p];
+    const double cost = (a.p0 && a.p0[p] == 0) ? 0.0 : smc_user_ieee::smc_user_cost(th);
+    const bool on_list = cost > SMC_USER_LIST_COST;     // false for NaN
+    a.listed[p] = on_list ? 1 : 0;
+    if (!on_list) return;
+    if (cost > SMC_USER_SOLO_COST) {
+        const unsigned k = atomicAdd(a.count + 1, 1u);
+        if (k < a.solo_cap) {
+            a.stiff_list[a.stiff_cap - 1 - (long long)k] = (int)p;
+            return;
+        }
+    }
+    a.stiff_list[atomicAdd(a.count, 1u)] = (int)p;
+}
+#endif
 )SRC";
 
 // log-likelihood of Micmem_likelihood.py:62-73 per particle from the per-item sums; counters as in the built-in path
@@ -427,6 +536,11 @@ user_finish_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, 
 struct UserModel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
+    hipFunction_t fn_scan = nullptr;      // smc_user_cost_scan_kernel: only for a source that defines smc_user_cost
+    int32_t *d_list = nullptr;            // the two lists of a sweep (n_local entries), their flags and two alternating counter pairs
+    uint8_t *d_listed = nullptr;
+    unsigned *d_count = nullptr;
+    int parity = 0;
     double *d_t = nullptr, *d_obs = nullptr, *d_cond = nullptr, *d_sum = nullptr;
     int *d_info = nullptr;
     int n_ex = 0, n_t = 0, n_cond = 0, n_states = 0, est_sigma = 1;
@@ -434,10 +548,16 @@ struct UserModel {
     double sigma_fixed = 0, rtol = 1e-3, atol = 1e-6;
 };
 
+// the optional fourth ingredient: a source that mentions smc_user_cost must define it (include/smc_hip.h)
+static bool has_cost_hint(const char *user_source) { return strstr(user_source, "smc_user_cost") != nullptr; }
+
 static std::string build_source(const char *user_source, int n_states, int dim) {
-    char head[128];
-    snprintf(head, sizeof head, "#define SMC_USER_NS %d\n#define SMC_USER_DIM %d\n", n_states, dim);
-    return std::string(head) + user_source + "\n" + kUserKernelSource;
+    char head[256];
+    snprintf(head, sizeof head, "#define SMC_USER_NS %d\n#define SMC_USER_DIM %d\n%s", n_states, dim,
+             has_cost_hint(user_source) ? "#define SMC_USER_HAS_COST 1\n#define SMC_USER_LIST_COST 220.0\n#define SMC_USER_SOLO_COST 3700.0\n" : "");
+    return std::string(head) + (strstr(user_source, "smc_div") ? "#define SMC_USER_USES_DIV 1\n" : "#define SMC_USER_USES_DIV 0\n") +
+           kUserPreludeLean + "#line 1 \"user_model\"\n" + user_source + "\n" + kUserPreludeIeee + "#line 1 \"user_model\"\n" + user_source +
+           "\n}  // namespace smc_user_ieee\n" + kUserKernelSource;
 }
 
 // compile for gfx950; on failure `log` holds hiprtc's diagnostics
@@ -477,6 +597,9 @@ void user_model_release(smc_ctx *c) {
     (void)hipFree(u->d_cond);
     (void)hipFree(u->d_sum);
     (void)hipFree(u->d_info);
+    (void)hipFree(u->d_list);
+    (void)hipFree(u->d_listed);
+    (void)hipFree(u->d_count);
     if (u->module) (void)hipModuleUnload(u->module);
     delete u;
     c->user = nullptr;
@@ -484,7 +607,7 @@ void user_model_release(smc_ctx *c) {
 
 // dynamic LDS of the compiled kernel: four waves' pools of started items, then the data times and observations
 static size_t user_lds_bytes(int n_states, int n_ex, int n_t) {
-    return ((size_t)4 * (2 * n_states + 6) * 64 + (size_t)2 * n_ex * n_t) * sizeof(double);
+    return ((size_t)4 * (2 * n_states + 6) * 64 + (size_t)2 * n_ex * (n_t + 1)) * sizeof(double);
 }
 
 static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, int64_t n, uint8_t *p0mask, double *lk,
@@ -510,12 +633,41 @@ static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, 
     a.info = u->d_info;
     a.queue = c->d_queue;
     a.rej = reject ? c->d_reject : nullptr;
-    // persistent grid: the waves take chunks of kChunk items until the queue is empty (solve_sched.h)
+    // persistent grid: the waves take chunks of kChunk items until the queue is empty (solve_sched.h); with a cost hint a
+    // small sweep gets a wave per item so that solo solves do not queue behind each other (as mm_kernels.hip: solve_grid_blocks)
+    const bool lists = u->fn_scan && c->stiff_first != 0;
     const int64_t chunks = (((n + 63) / 64) * 64 * u->n_ex + kChunk - 1) / kChunk;
+    const int64_t need = (chunks + 3) / 4 + (lists ? (n * u->n_ex + 3) / 4 : 0);
     int64_t blocks = (int64_t)c->cu_count * u->blocks_per_cu;
-    if (blocks > (chunks + 3) / 4) blocks = (chunks + 3) / 4;
+    if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     const unsigned lds = (unsigned)user_lds_bytes(u->n_states, u->n_ex, u->n_t);
+    if (lists) {
+        u->parity ^= 1;
+        UserScanArgs sa{};
+        sa.theta = theta;
+        sa.stride = stride;
+        sa.n = n;
+        sa.p0 = p0mask;
+        sa.listed = u->d_listed;
+        sa.stiff_list = u->d_list;
+        sa.count = u->d_count + 2 * u->parity;
+        sa.count_next = u->d_count + 2 * (u->parity ^ 1);
+        sa.stiff_cap = c->n_local;
+        sa.solo_cap = (unsigned)(blocks * 4 / u->n_ex);      // one solo solve per wave of the grid
+        void *sargs[] = {&sa};
+        const hipError_t e = hipModuleLaunchKernel(u->fn_scan, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, sargs, nullptr);
+        if (e != hipSuccess) {
+            smc_fail(c, (std::string("launch of the user-model cost scan failed: ") + hipGetErrorString(e)).c_str());
+            c->launch_failed = true;
+            return;
+        }
+        a.listed = u->d_listed;
+        a.stiff_list = u->d_list;
+        a.stiff_count = sa.count;
+        a.stiff_cap = sa.stiff_cap;
+        a.solo_cap = sa.solo_cap;
+    }
     void *args[] = {&a};
     {
         ScopedTimer tm(c, SMC_T_SOLVE);
@@ -572,6 +724,20 @@ int smc_user_model_check(const char *source, int n_states, int dim, char *log, i
     return ok ? 0 : 1;
 }
 
+int smc_user_model_dump_source(const char *source, int n_states, int dim, const char *dir) {
+    if (!source || !dir || n_states < 1 || n_states > SMC_USER_MAX_STATES || dim < 1 || dim > SMC_MAX_DIM) return 2;
+    const std::string src = build_source(source, n_states, dim);
+    const char *names[] = {"smc_user_model.hip", "sweep_args.h", "philox.h", "solve_sched.h", "rk45_math.h"};
+    const char *texts[] = {src.c_str(), k_sweep_args_h, k_philox_h, k_solve_sched_h, k_rk45_math_h};
+    for (int i = 0; i < 5; ++i) {
+        FILE *f = fopen((std::string(dir) + "/" + names[i]).c_str(), "w");
+        if (!f) return 1;
+        const bool ok = fputs(texts[i], f) >= 0;
+        if (fclose(f) != 0 || !ok) return 1;
+    }
+    return 0;
+}
+
 int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const double *t, const double *obs, const double *cond,
                        int n_ex, int n_t, int n_cond, int est_sigma, double sigma_fixed, double rtol, double atol) {
     if (!c) return smc_fail(nullptr, "NULL context");
@@ -595,6 +761,10 @@ int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const doubl
         user_model_release(c);
         return smc_fail(c, "smc_set_model_user: loading the compiled module failed");
     }
+    if (has_cost_hint(source) && hipModuleGetFunction(&u->fn_scan, u->module, "smc_user_cost_scan_kernel") != hipSuccess) {
+        user_model_release(c);
+        return smc_fail(c, "smc_set_model_user: the source mentions smc_user_cost but the scan kernel is missing from the module");
+    }
     const size_t nt = (size_t)n_ex * n_t * sizeof(double), nc = (size_t)n_ex * (n_cond > 0 ? n_cond : 1) * sizeof(double);
     bool ok = hipMalloc(&u->d_t, nt) == hipSuccess && hipMalloc(&u->d_obs, nt) == hipSuccess && hipMalloc(&u->d_cond, nc) == hipSuccess;
     ok = ok && hipMemcpy(u->d_t, t, nt, hipMemcpyHostToDevice) == hipSuccess &&
@@ -603,6 +773,10 @@ int smc_set_model_user(smc_ctx *c, const char *source, int n_states, const doubl
     if (ok && !c->d_mlk2) ok = hipMalloc(&c->d_mlk2, (size_t)c->n_local * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc(&u->d_sum, (size_t)c->n_local * n_ex * sizeof(double)) == hipSuccess &&
          hipMalloc(&u->d_info, (size_t)c->n_local * n_ex * sizeof(int)) == hipSuccess;
+    if (ok && u->fn_scan)
+        ok = hipMalloc(&u->d_list, (size_t)c->n_local * sizeof(int32_t)) == hipSuccess &&
+             hipMalloc(&u->d_listed, (size_t)c->n_local) == hipSuccess && hipMalloc(&u->d_count, 4 * sizeof(unsigned)) == hipSuccess &&
+             hipMemset(u->d_count, 0, 4 * sizeof(unsigned)) == hipSuccess;
     if (!ok) {
         user_model_release(c);
         return smc_fail(c, "smc_set_model_user: device allocation / upload failed");

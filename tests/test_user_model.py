@@ -14,9 +14,14 @@ def _check(pkg, src, ns, dim):
 
 
 def test_example_sources_compile_for_gfx950(pkg):
-    for src, ns in ((pkg.user_models.MICHAELIS_MENTEN, 1), (pkg.user_models.CONSECUTIVE_REACTIONS, 2)):
+    for src, ns in ((pkg.user_models.MICHAELIS_MENTEN, 1), (pkg.user_models.MICHAELIS_MENTEN_PLAIN, 1),
+                    (pkg.user_models.CONSECUTIVE_REACTIONS, 2)):
         rc, log = _check(pkg, src, ns, 3)
         assert rc == 0, log
+    assert "smc_user_cost" in pkg.user_models.MICHAELIS_MENTEN and "smc_user_cost" not in pkg.user_models.MICHAELIS_MENTEN_PLAIN
+    # a source that names the cost hint must define it (include/smc_hip.h)
+    rc, log = _check(pkg, pkg.user_models.MICHAELIS_MENTEN_PLAIN + "// smc_user_cost: to do\n", 1, 3)
+    assert rc == 1 and "smc_user_cost" in log
 
 
 def test_broken_source_reports_the_compiler_log(pkg):
@@ -46,6 +51,47 @@ def test_mm_as_user_model_equals_builtin_kernel(pkg, data):
     assert info_a["n_failed"] == 0 and info_b["n_failed"] == 0
     assert info_a["rk_attempts"] == info_b["rk_attempts"]                  # the same step sequence, attempt for attempt
     assert np.max(np.abs(lk_a - lk_b) / np.maximum(1.0, np.abs(lk_a))) < 1e-10   # sum of squares: sequential here, NumPy-pairwise in the built-in kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [5, 64, 3000])
+def test_cost_hint_changes_the_order_of_the_solves_and_no_result(pkg, data, n):
+    """smc_user_cost (include/smc_hip.h): the hinted model hands its long solves out first and runs the longest one per wave;
+    likelihoods, attempt totals, and a Metropolis sweep with exact early rejection (accept flags, particles) must equal the
+    plain model's bit for bit - for a grid of a few waves as for a full one.  The population reaches Vmax/Km = 5000, so both
+    lists are in use; half of the proposals leave the prior's support (masked, never listed)."""
+    rs = np.random.RandomState(n)
+    th = np.column_stack([rs.uniform(0.5, 10, n), 10.0 ** rs.uniform(-3.3, 1, n), rs.uniform(0.01, 1, n)])
+    th[0] = (9.0, 0.002, 0.5)                                              # 4500: certainly a solo solve
+    out = {}
+    for name, src in (("plain", pkg.user_models.MICHAELIS_MENTEN_PLAIN), ("hint", pkg.user_models.MICHAELIS_MENTEN),
+                      ("hint, lists off", pkg.user_models.MICHAELIS_MENTEN)):
+        with pkg.HipEngine(n, 3, device=0) as eng:
+            eng.set_prior(pkg.SMCSettings().priors)
+            eng.set_model_user(src, 1, data.t, data.P_obs, cond=np.asarray(data.S0)[:, None])
+            if name.endswith("off"):
+                eng.set_stiff_first(False)
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            info = eng.loglik(pkg.SMC_SET_PRED)
+            lk = eng.download_lk(pkg.SMC_SET_PRED)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, lk)
+            eng.set_early_reject(False)
+            mh0 = eng.mh_step_device_rng(0.05, 1.0, np.diag([2.0, 0.5, 0.1]), 7, 3)
+            p0, l0 = eng.download_particles(pkg.SMC_SET_FILT), eng.download_lk(pkg.SMC_SET_FILT)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, lk)
+            eng.set_early_reject(True)
+            mh1 = eng.mh_step_device_rng(0.05, 1.0, np.diag([2.0, 0.5, 0.1]), 7, 3)
+            p1, l1 = eng.download_particles(pkg.SMC_SET_FILT), eng.download_lk(pkg.SMC_SET_FILT)
+        assert info["n_failed"] == 0 and mh0["n_failed"] == 0
+        assert np.array_equal(p0, p1) and np.array_equal(l0, l1) and mh0["accepted_now"] == mh1["accepted_now"]
+        assert mh1["rk_attempts"] <= mh0["rk_attempts"]
+        out[name] = (info["rk_attempts"], lk, mh0["accepted_now"], mh0["rk_attempts"], p0, l0)
+    for name in ("hint", "hint, lists off"):
+        assert out[name][0] == out["plain"][0] and out[name][2] == out["plain"][2] and out[name][3] == out["plain"][3], name
+        assert np.array_equal(out[name][1], out["plain"][1]) and np.array_equal(out[name][4], out["plain"][4]), name
+        assert np.array_equal(out[name][5], out["plain"][5]), name
 
 
 @pytest.mark.gpu

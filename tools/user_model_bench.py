@@ -13,15 +13,16 @@ for label, th in (("posterior-like", np.array([1.2254, 0.5218, 0.02048]) + rs.st
     with pkg.HipEngine(n, 3, device=0) as eng:
         eng.set_prior(pkg.SMCSettings().priors)
         eng.upload_particles(pkg.SMC_SET_PRED, th)
-        for name in ("built-in", "user"):
+        for name in ("built-in", "user", "user, no cost hint"):
             if name == "built-in":
                 eng.set_model_mm(t, P_obs, S0)
             else:
-                eng.set_model_user(pkg.user_models.MICHAELIS_MENTEN, 1, t, P_obs, cond=np.asarray(S0)[:, None])
+                src = pkg.user_models.MICHAELIS_MENTEN if name == "user" else pkg.user_models.MICHAELIS_MENTEN_PLAIN
+                eng.set_model_user(src, 1, t, P_obs, cond=np.asarray(S0)[:, None])
             eng.loglik(pkg.SMC_SET_PRED)
             eng.synchronize()
             t0 = time.perf_counter()
             info = eng.loglik(pkg.SMC_SET_PRED)
             eng.synchronize()
             dt = time.perf_counter() - t0
-            print(f"{label:15s} {name:8s}: {dt*1e3:8.2f} ms per sweep of {n} particles ({n/dt:.3g} particles/s, {info['rk_attempts']/dt/1e9:.2f} G attempts/s)", flush=True)
+            print(f"{label:15s} {name:18s}: {dt*1e3:8.2f} ms per sweep of {n} particles ({n/dt:.3g} particles/s, {info['rk_attempts']/dt/1e9:.2f} G attempts/s)", flush=True)
