@@ -97,7 +97,13 @@ int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *gu
  * Sweeps then hand the solves of particles above 220 attempts out before the index-ordered ones and run those above 3700
  * one per wave on wave-uniform operands (the built-in Michaelis-Menten kernel's stiff list and solo phase, smc_set_stiff_first
  * switches both off) - a sweep over a prior population is bounded by its longest serial solve, which should start first.
- * The hint changes the order of independent solves only, never a result; it may be crude, and NaN counts as cheap. */
+ * The hint changes the order of independent solves only, never a result; it may be crude, and NaN counts as cheap.
+ * The functions may call   double smc_div(double a, double b)   for a / b: the source is compiled twice, in two namespaces
+ * (so: device functions and constants only, nothing extern "C") - once with the six-operation division of the built-in
+ * kernel (v_rcp, one Newton step, one correction: equal to a / b bit for bit for normal operands and quotients, NaN where a / b
+ * needs a subnormal or infinite divisor or a * (1 / b) overflows), once with IEEE division; a step attempt runs on the first
+ * and is repeated on the second whenever its error norm is not finite.  smc_user_y0, smc_user_obs and smc_user_cost always
+ * run with IEEE division. */
 #define SMC_USER_MAX_STATES 8
 int smc_set_model_user(smc_ctx *ctx, const char *source, int n_states, const double *t, const double *obs, const double *cond,
                        int n_ex, int n_t, int n_cond, int est_sigma, double sigma_fixed, double rtol, double atol);
