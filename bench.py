@@ -448,6 +448,8 @@ def main():
                     help="A/B switch: hand the (particle, experiment) solves out in plain index order (SMCSettings.stiff_first)")
     ap.add_argument("--no-in-phase", action="store_true",
                     help="A/B switch: never let a wave wait for all of its lanes before a hand-out (SMCSettings.in_phase)")
+    ap.add_argument("--no-fast-tail", action="store_true",
+                    help="A/B switch: lone chains run the compiled step function, not the hand-written loop (smc_set_fast_tail)")
     ap.add_argument("--progress", action="store_true",
                     help="methanation only: one line per sweep on stderr and in gpurun_out/bench_methanation_progress.log")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -474,6 +476,7 @@ def main():
     eng = pkg.HipEngine(n_local, 3, device=dev, n_global=n_global)
     eng.set_model_mm(t, P_obs, S0)
     eng.set_prior(s.priors)
+    eng.set_fast_tail(not args.no_fast_tail)
     comm = make_comm(pkg, eng, rank, world)
 
     def one_run(i):

@@ -168,6 +168,13 @@ int smc_set_early_reject(smc_ctx *ctx, int enable);
  * scheduler too; 0 restores round 2's plain index order (A/B timing, tests).  Methanation: the same switch selects the
  * misfit order of the experiments in the early-rejection sweeps (smc_meth_sweep_check). */
 int smc_set_stiff_first(smc_ctx *ctx, int enable);
+/* A Michaelis-Menten solve that runs alone in its wave (a solo solve, the last survivor of a sweep) performs the attempts that
+ * neither produce an output nor meet a special case in a hand-written instruction sequence (csrc/mm_rk45.h:
+ * mm_fast_uniform_attempts: ~140 instead of ~190 instructions per attempt, the Dormand-Prince tableau resident in scalar
+ * registers); every other attempt goes through the compiled step function.  Default: on.  The results are the same bit for
+ * bit (tests/test_gpu_parity.py compares on and off); 0 is for that comparison and for A/B timing.  Parity mode
+ * (smc_set_exact_pow) never uses it. */
+int smc_set_fast_tail(smc_ctx *ctx, int enable);
 /* Michaelis-Menten Metropolis sweeps over a homogeneous population (the previous sweep of the context had fewer than one
  * (particle, experiment) solve in 20 000 with more than 64 RK45 attempts - counted on the device) run their waves IN PHASE
  * (default: on): a wave waits up to 12 attempts for all 64 lanes to finish before it starts its next 64 items, so that the

@@ -57,6 +57,7 @@ SIGNATURES = {
     "smc_set_resampling": (cint, [c_ctx, cint]),
     "smc_set_early_reject": (cint, [c_ctx, cint]),
     "smc_set_stiff_first": (cint, [c_ctx, cint]),
+    "smc_set_fast_tail": (cint, [c_ctx, cint]),
     "smc_set_in_phase": (cint, [c_ctx, cint]),
     "smc_set_exact_pow": (cint, [c_ctx, cint]),
     "smc_exchange_plan": (cint, [cint, cint, i64, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p, c_i64p]),

@@ -200,6 +200,7 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     int64_t stiff_cap;
     unsigned solo_cap;
     int patience;               // solve_sched.h: attempts a wave waits for all its lanes before a hand-out (homogeneous sweeps)
+    int fast_tail;              // lone chains run the hand-written attempt loop (mm_rk45.h: mm_fast_uniform_attempts; smc_set_fast_tail)
 };
 
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
@@ -346,6 +347,30 @@ struct MMOps {
     }
     __device__ __forceinline__ int attempt(Item &it) const {
         return mm_item_attempt<WRITE_PRED, kDivLean6, EXACT>(it.s, s_tp, n_t, rtol, atol, it.pred);
+    }
+    // The lone chain (solve_sched.h: solo phase, uniform tail): the hand-written loop of mm_rk45.h for the attempts of a stiff
+    // solve that neither produce an output nor hit a special case, mm_item_attempt for the others.  The block is entered only
+    // where it pays - the next data time at least four steps away (an attempt that turns out to need an output is computed
+    // twice) - and never in parity mode (its arithmetic is the default mode's).
+    __device__ __forceinline__ int uniform_attempts(Item &it, int budget) const {
+        if (EXACT || !a.fast_tail) return uniform_attempts_plain(*this, it, budget);
+        int st = 0;
+        do {
+            SMC_ISA_MARK("uniform_tail_attempt");
+            MMItem &s = it.s;
+            if (s.t_next - s.t > 4.0 * s.h_abs && s.attempts + budget < RK_MAX_ATTEMPTS) {
+                const int more = mm_fast_uniform_attempts(s, rtol, atol, budget);
+                // the block's results come back in vector registers: tell the compiler that they are wave-uniform
+                s.t = lane_value(s.t, 0);
+                s.y = lane_value(s.y, 0);
+                s.f = lane_value(s.f, 0);
+                s.h_abs = lane_value(s.h_abs, 0);
+                s.min_step = lane_value(s.min_step, 0);
+                if (!more) break;          // budget used up
+            }
+            st = attempt(it);
+        } while (st == 0 && --budget > 0);
+        return st;
     }
     __device__ __forceinline__ void finish(Item &it, int st) const {
         const bool ok = (st == 1) && (it.s.i_out == n_t);
@@ -596,6 +621,7 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.stiff_cap = sl.cap;
     a.solo_cap = sl.solo_cap;
     a.patience = patience;
+    a.fast_tail = ctx->fast_tail;
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
     const bool exact = ctx->exact_pow != 0;

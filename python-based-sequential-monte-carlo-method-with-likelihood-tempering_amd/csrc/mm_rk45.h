@@ -312,6 +312,219 @@ __device__ __forceinline__ int mm_item_attempt(MMItem &it, const double2 *s_tp, 
     return (accept && (t_new - it.t_bound >= 0)) ? 1 : 0;  // base.py:196
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The lone chain, by hand.  A stiff solve that runs alone in its wave (solve_sched.h: solo phase, uniform tail) is the serial
+// critical path of every early sweep: ~10^5 dependent attempts, each a chain of ~190 compiler-scheduled instructions of which
+// a lone wave issues one per >= 4 clocks whatever they are (0.43 us per attempt).  ~100 of them are the Runge-Kutta stages,
+// which the compiler does well; the other ~90 are step control written as selects for the per-lane case (two v_cndmask per
+// double), scalar bookkeeping and Dormand-Prince constants re-materialised with s_mov pairs because the tableau does not
+// fit beside the scheduler's state.  mm_fast_uniform_attempts() is that loop as ONE inline-asm block for the common case
+// of a stiff chain - an attempt that is rejected, or accepted without a data time in (t, t_new] - with the tableau in
+// scalar registers for the whole loop, branches instead of selects (every operand is wave-uniform) and no bookkeeping:
+// ~140 instructions per attempt.  Anything else - an output is due, the step size underflows, the error norm leaves
+// 2^-64 .. 2^64 (zero, inf and NaN included: the lean division's re-run, the controller's special cases) - leaves the
+// block BEFORE the attempt is committed, and mm_item_attempt() performs that attempt from the same state.
+// Bit-identical to mm_item_attempt<., kDivLean6, false> by construction: the same operations in the same order with the
+// same fused multiply-adds the compiler forms for rk_attempt_core (first two terms of a stage sum: fma(k0, a_i1, rn(k1 *
+// a_i2)), the others fused in order; (sum) * h + y fused) - tests/test_gpu_parity.py runs stiff populations with the block
+// on and off (smc_set_fast_tail) and demands equal bits, so a compiler that changes its mind is noticed.
+// Hazards the assembler does not see inside an asm block (gfx940 rules of LLVM's hazard recogniser): one independent
+// instruction or s_nop between a transcendental (v_rcp_f64, v_log_f32, v_exp_f32) and the first use of its result.
+// Returns 1 when the next attempt needs mm_item_attempt() (state untouched by it), 0 when `budget` ran out.
+// the first lane's value in a scalar register pair: for operands that are wave-uniform by construction
+__device__ __forceinline__ double mm_uniform(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ int mm_fast_uniform_attempts(MMItem &it, double rtol, double atol, int &budget) {
+    double t = it.t, y = it.y, k0 = it.f, habs = it.h_abs, minstep = it.min_step;
+    // scalar-register operands of the block: wave-uniform by construction, the v_readfirstlane says so to the compiler
+    const double nvm = mm_uniform(it.negVmax), km = mm_uniform(it.Km), tb = mm_uniform(it.t_bound);
+    const double tstop = mm_uniform(fmin(it.t_next, it.t_bound));   // the first time the block must not step over
+    atol = mm_uniform(atol);
+    // wave-uniform by construction; the readfirstlane makes them so for the compiler (scalar-register operands of the block)
+    int attempts = __builtin_amdgcn_readfirstlane(it.attempts), rejected = __builtin_amdgcn_readfirstlane(it.rejected ? 1 : 0), code;
+    budget = __builtin_amdgcn_readfirstlane(budget);
+    double tnew, h, k1, k2, k3, k4, k5, k6, acc, den, num, r, e, q;   // k1 doubles as y_new (b2 = e2 = 0), acc as the factor
+    float w;
+    unsigned long long accm;
+    asm volatile(
+        "s_mov_b32 %[code], 1\n"
+        ".Lfast_loop_%=:\n"
+        "v_cmp_lt_f64 vcc, %[habs], %[minstep]\n"             // rk.py:133-134: left to mm_item_attempt
+        "s_cbranch_vccnz .Lfast_end_%=\n"
+        "v_add_f64 %[tnew], %[t], %[habs]\n"
+        "v_min_f64 %[tnew], %[tnew], %[tb]\n"
+        "v_add_f64 %[h], %[tnew], -%[t]\n"
+        // stage 1
+        "v_mul_f64 %[acc], %[k0], %[a21]\n"
+        "v_fma_f64 %[acc], %[acc], %[h], %[y]\n"
+        "v_add_f64 %[den], %[km], %[acc]\n"
+        "v_rcp_f64 %[r], %[den]\n"
+        "v_mul_f64 %[num], %[nvm], %[acc]\n"
+        "v_fma_f64 %[e], -%[den], %[r], 1.0\n"
+        "v_fma_f64 %[r], %[r], %[e], %[r]\n"
+        "v_mul_f64 %[q], %[num], %[r]\n"
+        "v_fma_f64 %[e], -%[den], %[q], %[num]\n"
+        "v_fma_f64 %[k1], %[e], %[r], %[q]\n"
+        // stage 2
+        "v_mul_f64 %[acc], %[k1], %[a32]\n"
+        "v_fma_f64 %[acc], %[k0], %[a31], %[acc]\n"
+        "v_fma_f64 %[acc], %[acc], %[h], %[y]\n"
+        "v_add_f64 %[den], %[km], %[acc]\n"
+        "v_rcp_f64 %[r], %[den]\n"
+        "v_mul_f64 %[num], %[nvm], %[acc]\n"
+        "v_fma_f64 %[e], -%[den], %[r], 1.0\n"
+        "v_fma_f64 %[r], %[r], %[e], %[r]\n"
+        "v_mul_f64 %[q], %[num], %[r]\n"
+        "v_fma_f64 %[e], -%[den], %[q], %[num]\n"
+        "v_fma_f64 %[k2], %[e], %[r], %[q]\n"
+        // stage 3
+        "v_mul_f64 %[acc], %[k1], %[a42]\n"
+        "v_fma_f64 %[acc], %[k0], %[a41], %[acc]\n"
+        "v_fma_f64 %[acc], %[k2], %[a43], %[acc]\n"
+        "v_fma_f64 %[acc], %[acc], %[h], %[y]\n"
+        "v_add_f64 %[den], %[km], %[acc]\n"
+        "v_rcp_f64 %[r], %[den]\n"
+        "v_mul_f64 %[num], %[nvm], %[acc]\n"
+        "v_fma_f64 %[e], -%[den], %[r], 1.0\n"
+        "v_fma_f64 %[r], %[r], %[e], %[r]\n"
+        "v_mul_f64 %[q], %[num], %[r]\n"
+        "v_fma_f64 %[e], -%[den], %[q], %[num]\n"
+        "v_fma_f64 %[k3], %[e], %[r], %[q]\n"
+        // stage 4
+        "v_mul_f64 %[acc], %[k1], %[a52]\n"
+        "v_fma_f64 %[acc], %[k0], %[a51], %[acc]\n"
+        "v_fma_f64 %[acc], %[k2], %[a53], %[acc]\n"
+        "v_fma_f64 %[acc], %[k3], %[a54], %[acc]\n"
+        "v_fma_f64 %[acc], %[acc], %[h], %[y]\n"
+        "v_add_f64 %[den], %[km], %[acc]\n"
+        "v_rcp_f64 %[r], %[den]\n"
+        "v_mul_f64 %[num], %[nvm], %[acc]\n"
+        "v_fma_f64 %[e], -%[den], %[r], 1.0\n"
+        "v_fma_f64 %[r], %[r], %[e], %[r]\n"
+        "v_mul_f64 %[q], %[num], %[r]\n"
+        "v_fma_f64 %[e], -%[den], %[q], %[num]\n"
+        "v_fma_f64 %[k4], %[e], %[r], %[q]\n"
+        // stage 5
+        "v_mul_f64 %[acc], %[k1], %[a62]\n"
+        "v_fma_f64 %[acc], %[k0], %[a61], %[acc]\n"
+        "v_fma_f64 %[acc], %[k2], %[a63], %[acc]\n"
+        "v_fma_f64 %[acc], %[k3], %[a64], %[acc]\n"
+        "v_fma_f64 %[acc], %[k4], %[a65], %[acc]\n"
+        "v_fma_f64 %[acc], %[acc], %[h], %[y]\n"
+        "v_add_f64 %[den], %[km], %[acc]\n"
+        "v_rcp_f64 %[r], %[den]\n"
+        "v_mul_f64 %[num], %[nvm], %[acc]\n"
+        "v_fma_f64 %[e], -%[den], %[r], 1.0\n"
+        "v_fma_f64 %[r], %[r], %[e], %[r]\n"
+        "v_mul_f64 %[q], %[num], %[r]\n"
+        "v_fma_f64 %[e], -%[den], %[q], %[num]\n"
+        "v_fma_f64 %[k5], %[e], %[r], %[q]\n"
+        // y_new and k6 = f(y_new)
+        "v_mul_f64 %[acc], %[k2], %[b3]\n"
+        "v_fma_f64 %[acc], %[k0], %[b1], %[acc]\n"
+        "v_fma_f64 %[acc], %[k3], %[b4], %[acc]\n"
+        "v_fma_f64 %[acc], %[k4], %[b5], %[acc]\n"
+        "v_fma_f64 %[acc], %[k5], %[b6], %[acc]\n"
+        "v_fma_f64 %[k1], %[h], %[acc], %[y]\n"
+        "v_add_f64 %[den], %[km], %[k1]\n"
+        "v_rcp_f64 %[r], %[den]\n"
+        "v_mul_f64 %[num], %[nvm], %[k1]\n"
+        "v_fma_f64 %[e], -%[den], %[r], 1.0\n"
+        "v_fma_f64 %[r], %[r], %[e], %[r]\n"
+        "v_mul_f64 %[q], %[num], %[r]\n"
+        "v_fma_f64 %[e], -%[den], %[q], %[num]\n"
+        "v_fma_f64 %[k6], %[e], %[r], %[q]\n"
+        // error estimate over the scale: den = atol + max(|y|, |y_new|) * rtol, num = (sum e_j k_j) * h, q = num / den
+        "v_max_f64 %[den], |%[y]|, |%[k1]|\n"
+        "v_fma_f64 %[den], %[rtol], %[den], %[atol]\n"
+        "v_rcp_f64 %[r], %[den]\n"
+        "v_mul_f64 %[acc], %[k2], %[e3]\n"
+        "v_fma_f64 %[acc], %[k0], %[e1], %[acc]\n"
+        "v_fma_f64 %[acc], %[k3], %[e4], %[acc]\n"
+        "v_fma_f64 %[acc], %[k4], %[e5], %[acc]\n"
+        "v_fma_f64 %[acc], %[k5], %[e6], %[acc]\n"
+        "v_fma_f64 %[acc], %[k6], %[e7], %[acc]\n"
+        "v_mul_f64 %[num], %[h], %[acc]\n"
+        "v_fma_f64 %[e], -%[den], %[r], 1.0\n"
+        "v_fma_f64 %[r], %[r], %[e], %[r]\n"
+        "v_mul_f64 %[q], %[r], %[num]\n"
+        "v_fma_f64 %[e], -%[den], %[q], %[num]\n"
+        "v_fma_f64 %[q], %[e], %[r], %[q]\n"                  // error_norm = |q|
+        // 0.9 * error_norm ** -0.2: pow_minus_fifth_core<false> (rk45_math.h)
+        "v_cvt_f32_f64 %[w], |%[q]|\n"
+        "v_cmp_lt_f64 %[accm], |%[q]|, 1.0\n"                 // accept (rk.py:149)
+        "v_log_f32 %[w], %[w]\n"
+        "s_nop 0\n"
+        "v_mul_f32 %[w], 0xbe4ccccd, %[w]\n"
+        "v_exp_f32 %[w], %[w]\n"
+        "s_nop 0\n"
+        "v_cvt_f64_f32 %[r], %[w]\n"                          // y
+        "v_mul_f64 %[e], %[r], %[r]\n"
+        "v_mul_f64 %[e], %[e], %[e]\n"
+        "v_mul_f64 %[e], %[e], %[r]\n"                        // y^5
+        "v_fma_f64 %[e], -|%[q]|, %[e], 1.0\n"                // rho
+        "v_mul_f64 %[acc], %[e], %[r]\n"                      // y * rho
+        "v_fma_f64 %[e], %[c012], %[e], %[c02]\n"             // 0.2 + 0.12 rho
+        "v_fma_f64 %[r], %[acc], %[e], %[r]\n"
+        "v_mul_f64 %[acc], %[r], %[c09]\n"
+        "s_and_b64 vcc, exec, %[accm]\n"
+        "s_cbranch_vccz .Lfast_reject_%=\n"
+        // ---- accepted: no output may be due (tstop = min(t_next, t_bound)) and error_norm >= 2^-64
+        "v_cmp_le_f64 vcc, %[tstop], %[tnew]\n"
+        "s_cbranch_vccnz .Lfast_end_%=\n"
+        "v_cmp_nge_f64 vcc, |%[q]|, %[clo]\n"
+        "s_cbranch_vccnz .Lfast_end_%=\n"
+        "v_min_f64 %[acc], %[acc], %[c10]\n"                    // min(MAX_FACTOR, .)
+        "s_cmp_eq_u32 %[rejected], 0\n"
+        "s_cbranch_scc1 .Lfast_first_%=\n"
+        "v_min_f64 %[acc], %[acc], 1.0\n"                       // rk.py:158-159
+        ".Lfast_first_%=:\n"
+        "v_mul_f64 %[habs], |%[h]|, %[acc]\n"
+        "v_mov_b64 %[t], %[tnew]\n"
+        "v_mov_b64 %[y], %[k1]\n"
+        "v_mov_b64 %[k0], %[k6]\n"
+        "s_mov_b32 %[rejected], 0\n"
+        "v_lshl_add_u64 %[e], %[tnew], 0, 1\n"                // min_step = 10 |nextafter(t, inf) - t|, t >= 0 (rk.py:120)
+        "v_add_f64 %[e], %[e], -%[tnew]\n"
+        "v_mul_f64 %[minstep], |%[e]|, %[c10]\n"
+        "v_max_f64 %[habs], %[habs], %[minstep]\n"            // rk.py:122-127
+        "s_branch .Lfast_next_%=\n"
+        ".Lfast_reject_%=:\n"
+        "v_cmp_nlt_f64 vcc, |%[q]|, %[chi]\n"                 // error_norm >= 2^64, inf or NaN: left to mm_item_attempt
+        "s_cbranch_vccnz .Lfast_end_%=\n"
+        "v_max_f64 %[acc], %[acc], %[c02]\n"                    // max(MIN_FACTOR, .)
+        "v_mul_f64 %[habs], |%[h]|, %[acc]\n"
+        "s_mov_b32 %[rejected], 1\n"
+        ".Lfast_next_%=:\n"
+        "s_add_i32 %[attempts], %[attempts], 1\n"
+        "s_sub_i32 %[budget], %[budget], 1\n"
+        "s_cmp_gt_i32 %[budget], 0\n"
+        "s_cbranch_scc1 .Lfast_loop_%=\n"
+        "s_mov_b32 %[code], 0\n"
+        ".Lfast_end_%=:\n"
+        : [t] "+v"(t), [y] "+v"(y), [k0] "+v"(k0), [habs] "+v"(habs), [minstep] "+v"(minstep), [attempts] "+s"(attempts),
+          [rejected] "+s"(rejected), [budget] "+s"(budget), [code] "=&s"(code), [tnew] "=&v"(tnew), [h] "=&v"(h), [k1] "=&v"(k1),
+          [k2] "=&v"(k2), [k3] "=&v"(k3), [k4] "=&v"(k4), [k5] "=&v"(k5), [k6] "=&v"(k6), [acc] "=&v"(acc),
+          [den] "=&v"(den), [num] "=&v"(num), [r] "=&v"(r), [e] "=&v"(e), [q] "=&v"(q), [w] "=&v"(w),
+          [accm] "=&s"(accm)
+        : [nvm] "s"(nvm), [km] "s"(km), [tb] "s"(tb), [tstop] "s"(tstop), [rtol] "v"(rtol), [atol] "s"(atol), [c02] "v"(0.2),
+          [a21] "s"(A21), [a31] "s"(A31), [a32] "s"(A32), [a41] "s"(A41), [a42] "s"(A42), [a43] "s"(A43), [a51] "s"(A51),
+          [a52] "s"(A52), [a53] "s"(A53), [a54] "s"(A54), [a61] "s"(A61), [a62] "s"(A62), [a63] "s"(A63), [a64] "s"(A64),
+          [a65] "s"(A65), [b1] "s"(B1), [b3] "s"(B3), [b4] "s"(B4), [b5] "s"(B5), [b6] "s"(B6), [e1] "s"(E1), [e3] "s"(E3),
+          [e4] "s"(E4), [e5] "s"(E5), [e6] "s"(E6), [e7] "s"(E7), [c09] "s"(0.9), [c10] "s"(10.0), [c012] "s"(0.12),
+          [clo] "s"(0x1p-64), [chi] "s"(0x1p64)
+        : "vcc", "scc");
+    it.t = t;
+    it.y = y;
+    it.f = k0;
+    it.h_abs = habs;
+    it.min_step = minstep;
+    it.attempts = attempts;
+    it.rejected = rejected != 0;
+    return code;
+}
+
 // Tried for the lone chain of the uniform tail and NOT adopted (round 3, tools/isa_blocks.py on the listings): (a) a twin
 // of this function with rk.py's own branches instead of the selects - bit-identical, 14 selects fewer, but inside the
 // scheduler the compiler then re-materialises 25 instead of 5 FP64 constants per attempt (51 s_mov_b32: 223 instructions per

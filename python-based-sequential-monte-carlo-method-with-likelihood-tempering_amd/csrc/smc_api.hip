@@ -406,6 +406,11 @@ int smc_set_in_phase(smc_ctx *c, int enable) {
     return 0;
 }
 
+int smc_set_fast_tail(smc_ctx *c, int enable) {
+    if (!c) return smc_fail(nullptr, "NULL context");
+    c->fast_tail = enable != 0;
+    return 0;
+}
 int smc_set_stiff_first(smc_ctx *c, int enable) {
     if (!c) return fail(nullptr, "NULL context");
     c->stiff_first = enable != 0;

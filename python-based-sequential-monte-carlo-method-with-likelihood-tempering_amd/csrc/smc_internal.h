@@ -172,6 +172,7 @@ struct smc_ctx {
     int32_t *d_stiff_list = nullptr;       // stiff list (item_cap entries) and its two alternating counters
     unsigned *d_stiff_count = nullptr;
     int stiff_parity = 0;
+    int fast_tail = 1;                     // hand-written lone-chain loop in the Michaelis-Menten solve kernel (smc_set_fast_tail)
     int stiff_first = 1;                   // hand the predictably long solves out first (smc_set_stiff_first)
     int in_phase = 1;                      // let homogeneous Metropolis sweeps run their waves in phase (solve_sched.h: patience)
     int64_t last_sweep_items = 0, last_sweep_long_items = 0, pending_sweep_items = 0;   // of the last finished MM Metropolis sweep

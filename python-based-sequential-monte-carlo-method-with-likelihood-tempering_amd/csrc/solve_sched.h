@@ -34,6 +34,8 @@
 //                                        particle of the list (from_list == false) - it has been handed out already
 //   void pack(const Item &, double *slot)   / void unpack(Item &, const double *slot)     slot[w * 64], w < kPoolWords
 //   int  attempt(Item &)                 one step attempt; 0 = still running, anything else = finished / failed
+//   int  uniform_attempts(Item &, int n) up to n attempts of an item whose state is wave-uniform, stopping at the first that
+//                                        does not return 0; returns the last status (uniform_attempts_plain() below, or better)
 //   void finish(Item &, int status)      publish the result
 //   Item broadcast(const Item &, int src)   the item of lane src in every lane (v_readlane on every field)
 //   int patience                         attempts a wave waits for ALL its lanes before a hand-out (0: none; see kRefillAt below)
@@ -101,6 +103,17 @@ __device__ __forceinline__ long long lane_value_ll(long long v, int src) {
                        (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src));
 }
 
+// Ops::uniform_attempts for a model without a hand-written lone-chain loop
+template <class Ops>
+__device__ __forceinline__ int uniform_attempts_plain(const Ops &ops, typename Ops::Item &u, int budget) {
+    int st;
+    do {
+        SMC_ISA_MARK("uniform_tail_attempt");
+        st = ops.attempt(u);
+    } while (st == 0 && --budget > 0);
+    return st;
+}
+
 // One item whose state is the same in every lane (wave-uniform), to the end: attempts in a tight loop of scalar branches,
 // and - in a Metropolis sweep - a look at the exact rejection bound before the first attempt and every kRejectCheckEvery.
 template <class Ops>
@@ -120,11 +133,7 @@ __device__ __forceinline__ void run_item_uniform(Ops &ops, typename Ops::Item &u
             cancelled = true;
             break;
         }
-        int budget = kRejectCheckEvery;
-        do {
-            SMC_ISA_MARK("uniform_tail_attempt");
-            st = ops.attempt(u);
-        } while (st == 0 && --budget > 0);
+        st = ops.uniform_attempts(u, kRejectCheckEvery);
         if (st != 0) break;
     }
     // Every lane holds the same result and stores it to the same address: one wave-wide store of 64 identical values

@@ -379,6 +379,7 @@ struct UserOps {
         if (it.attempts >= 0x1fffffffu) it.s.status = -1;        // hard bound so that every wave drains
         return it.s.status;
     }
+    __device__ __forceinline__ int uniform_attempts(Item &it, int budget) const { return smc::uniform_attempts_plain(*this, it, budget); }
     __device__ __forceinline__ void finish(Item &it, int st) const {
         publish(it.out_idx, it.s.sr2, (int)(it.attempts & 0x1fffffffu) | ((st < 0) ? (1 << 30) : 0));
     }

@@ -193,6 +193,12 @@ class HipEngine:
             return
         self._ck(self.L.smc_set_in_phase(self.ctx, int(bool(enable))), "smc_set_in_phase")
 
+    def set_fast_tail(self, enable=True):
+        """Hand-written lone-chain attempt loop of the Michaelis-Menten kernel (include/smc_hip.h: smc_set_fast_tail)."""
+        if "smc_set_fast_tail" in B.MISSING:       # A/B build of an earlier revision (SMC_HIP_LIB)
+            return
+        self._ck(self.L.smc_set_fast_tail(self.ctx, int(bool(enable))), "smc_set_fast_tail")
+
     def set_stiff_first(self, enable=True):
         """Hand the predictably long Michaelis-Menten solves out first (include/smc_hip.h: smc_set_stiff_first)."""
         if "smc_set_stiff_first" in B.MISSING:     # A/B build of a revision before the stiff list (SMC_HIP_LIB)

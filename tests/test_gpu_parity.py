@@ -1177,6 +1177,60 @@ def test_stiff_first_full_run_is_bit_identical(pkg, data):
     assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
 
 
+# ---------------------------------------------------------------------------------------------------
+# the hand-written lone-chain loop (smc_set_fast_tail; csrc/mm_rk45.h: mm_fast_uniform_attempts) against the compiled step function
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,seed", [(1, 0), (7, 1), (64, 2), (700, 3), (20000, 4)])
+def test_hand_written_lone_chain_loop_is_bit_identical_to_the_compiled_step(pkg, O, data, n, seed):
+    """The inline-asm attempt loop that solo solves and last survivors run must produce the bits of mm_item_attempt: same
+    operations, same order, same fused multiply-adds.  Populations in which every particle is stiff (Vmax / Km = 60 ... 2e4:
+    stiff list and solo list in use; with n = 1, 7, 64 every solve is a solo solve, i.e. runs in the block from its first
+    attempt to its last apart from the attempts that produce outputs), likelihood sweep with and without predictions, one
+    Metropolis sweep; logL, predictions, device-counted attempts, selected particles, accept flags: all equal with the block
+    on and off - and both within the stiff band's tolerance of the checker."""
+    rs = np.random.RandomState(seed)
+    th = rs.uniform(0.05, 10, (n, 3))
+    th[:, 1] = th[:, 0] / 10.0 ** rs.uniform(1.8, 4.3, n)
+    th[0] = (10.0, 3e-3, 1.0)                                           # tools/tail_latency.py's 12 562-attempt solve
+    noise = rs.standard_normal((n, 3)) * np.array([0.3, 1e-4, 0.3])
+    rr = rs.uniform(0, 1, n)
+    res = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            eng.set_fast_tail(on)
+            eng.set_early_reject(False)                                 # so that the attempt counts are deterministic too
+            lk_h, pred_h, info_h = eng.loglik_host(th, want_pred=True)
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            info = eng.loglik(pkg.SMC_SET_PRED)
+            lk = eng.download_lk(pkg.SMC_SET_PRED)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, lk)
+            out = eng.mh_step_host_rng(0.01, 1.0, noise, rr)
+            res[on] = (lk_h, pred_h, info_h["rk_attempts"], lk, info["rk_attempts"], out["rk_attempts"], out["accepted_now"],
+                       eng.download_particles(pkg.SMC_SET_FILT), eng.download_lk(pkg.SMC_SET_FILT), eng.download_accept_flags())
+    a, b = res[True], res[False]
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True), k
+    assert a[2] == a[4] and np.array_equal(a[0], a[3])
+    if n <= 700:
+        lk_ref, _, info_ref = O.mm_loglik_batch(th, data)
+        assert np.max(relerr(a[3], lk_ref)) < 1e-6 and abs(a[2] - info_ref["n_attempts"]) <= 1e-3 * info_ref["n_attempts"]
+
+
+def test_hand_written_lone_chain_loop_full_run_is_bit_identical(pkg, data):
+    """A complete device-RNG run (early rejection on, as in the benchmark) with the block on and off."""
+    n = 200_000
+    runs = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            eng.set_fast_tail(on)
+            runs[on] = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n), rng="device", verbose=False, seed_device=37)
+    a, b = runs[True], runs[False]
+    assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
+    assert [r_["n_accept"] for r_ in a["records"]] == [r_["n_accept"] for r_ in b["records"]]
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+
+
 @pytest.mark.parametrize("n_cand", [1, 5, 16, 17, 32])
 def test_fused_ess_search_equals_max_plus_partials(pkg, data, n_cand):
     """smc_ess_search_global (maximum + up to 32 candidates, ONE synchronisation; the ESS passes read max(lk) from device

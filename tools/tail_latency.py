@@ -12,8 +12,9 @@ for n_lanes in (1, 64, 4096):
     with pkg.HipEngine(max(n_lanes, 1), 3) as eng:
         mode = sys.argv[1] if len(sys.argv) > 1 else "built-in"
         th = np.tile(np.array([[10.0, 3e-3, 1.0]]), (n_lanes, 1))
-        if mode == "built-in":
+        if mode.startswith("built-in"):
             eng.set_model_mm(t, np.zeros((1, 40)), np.array([0.1]))
+            eng.set_fast_tail(mode != "built-in-nofast")          # the hand-written lone-chain loop (smc_set_fast_tail)
             run = lambda: eng.loglik_host(th)[2]                      # noqa: E731
         else:
             src = pkg.user_models.MICHAELIS_MENTEN if mode == "user" else pkg.user_models.MICHAELIS_MENTEN_PLAIN
