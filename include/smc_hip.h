@@ -203,6 +203,9 @@ int smc_upload_lk(smc_ctx *ctx, int set, const double *lk, int64_t n);
 int smc_download_lk(smc_ctx *ctx, int set, double *lk, int64_t n);
 /* r_ac, the ever-accepted flags of the current tempering step (Micmem_SMC_main.py:187,241). */
 int smc_download_accept_flags(smc_ctx *ctx, uint8_t *flags, int64_t n);
+/* Diagnostics (tools/sweep_tail_census.py): the per-(experiment, particle) record of the last Michaelis-Menten sweep over n
+ * particles, info[e * n + p] = RK45 attempts | cancelled by early rejection << 29 | failed << 30.  n_ex * n entries. */
+int smc_download_item_info(smc_ctx *ctx, int32_t *info, int64_t n);
 /* p_pred, lk = p_filt.copy(), lk1.copy() (Micmem_SMC_main.py:251-252): device-to-device. */
 int smc_commit_filt_to_pred(smc_ctx *ctx);
 /* Device-RNG prior draw into SMC_SET_PRED (replaces sample_prior, Micmem_settings.py:69-87, in

@@ -66,6 +66,7 @@ SIGNATURES = {
     "smc_upload_lk": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_download_lk": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_download_accept_flags": (cint, [c_ctx, c_u8p, i64]),
+    "smc_download_item_info": (cint, [c_ctx, ctypes.POINTER(ctypes.c_int32), i64]),
     "smc_commit_filt_to_pred": (cint, [c_ctx]),
     "smc_sample_prior_device": (cint, [c_ctx, u64, i64]),
     "smc_loglik": (cint, [c_ctx, cint, c_i64p, c_i64p]),

@@ -477,6 +477,15 @@ int smc_download_accept_flags(smc_ctx *c, uint8_t *flags, int64_t n) {
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+int smc_download_item_info(smc_ctx *c, int32_t *info, int64_t n) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (c->model_kind != 1 || !c->d_info || n < 0 || n > c->item_cap) return fail(c, "smc_download_item_info: Michaelis-Menten sweeps only, n <= particles of the last sweep");
+    HIPC(c, hipSetDevice(c->device));
+    // the last sweep wrote item (e, p) at e * n_sweep + p; the caller passes the particle count of that sweep
+    HIPC(c, hipMemcpyAsync(info, c->d_info, (size_t)n * c->mm.n_ex * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 int smc_reset_accept_flags(smc_ctx *c) {
     if (!c) return fail(nullptr, "NULL context");
     HIPC(c, hipSetDevice(c->device));

@@ -238,6 +238,13 @@ class HipEngine:
                  "smc_download_accept_flags")
         return out
 
+    def download_item_info(self, n=None):
+        """(n_ex, n) records of the last Michaelis-Menten sweep: attempts | cancelled << 29 | failed << 30 (diagnostics)."""
+        n = self.n_local if n is None else int(n)
+        out = np.empty((self.model[1], n), dtype=np.int32)
+        self._ck(self.L.smc_download_item_info(self.ctx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), n), "smc_download_item_info")
+        return out
+
     def commit_filt_to_pred(self):
         self._ck(self.L.smc_commit_filt_to_pred(self.ctx), "smc_commit_filt_to_pred")
 
