@@ -100,7 +100,7 @@ int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *gu
  * The hint changes the order of independent solves only, never a result; it may be crude, and NaN counts as cheap.
  * The functions may call   double smc_div(double a, double b)   for a / b: the source is compiled twice, in two namespaces
  * (so: device functions and constants only, nothing extern "C") - once with the six-operation division of the built-in
- * kernel (v_rcp, one Newton step, one correction: equal to a / b bit for bit for normal operands and quotients, NaN where a / b
+ * kernel (v_rcp, one Newton step, one correction: equal to a / b for normal operands and quotients up to a last bit in about one pair of 2^44, NaN where a / b
  * needs a subnormal or infinite divisor or a * (1 / b) overflows), once with IEEE division; a step attempt runs on the first
  * and is repeated on the second whenever its error norm is not finite.  smc_user_y0, smc_user_obs and smc_user_cost always
  * run with IEEE division. */

@@ -14,8 +14,11 @@ namespace smc {
 // a / b with a shorter dependent chain than the compiler's IEEE sequence (v_div_scale, v_rcp, two
 // Newton steps, v_div_fmas, v_div_fixup: ~30 ns on the chain).  v_rcp_f64 is accurate to 2^-24.4
 // (measured, tools/div_probe.hip), so ONE Newton step gives 2^-48.8 and the Markstein correction
-// q + (a - b*q)*r rounds correctly (the error of the sum before rounding is ~2^-97 relative):
-// bit-identical to a/b on 4M wide-exponent operand pairs and 4M right-hand-side-shaped ones, both forms:
+// q + (a - b*q)*r is within ~2^-97 relative of a/b before its single rounding: the rounded result is the correctly rounded
+// quotient unless a/b lies within that distance of a rounding boundary - about one operand pair in 2^44, i.e. a
+// percent-level chance per 10^6-particle run of ONE last-bit deviation from IEEE division somewhere, far inside every stated
+// tolerance; parity mode (EXACT) divides with the IEEE sequence.  Measured: bit-identical to a/b on 4M wide-exponent operand
+// pairs and 4M right-hand-side-shaped ones, both forms:
 //   lean_div6  rcp -> e -> r -> q = a*r -> rem -> result: six dependent operations, six instructions.  The product path.
 //   lean_div5  the Newton step applied to the QUOTIENT, q1 = q0 + q0*e with q0 = a*r0, beside the one on the reciprocal:
 //              rcp -> e -> q1 -> rem -> result, five dependent operations but seven instructions.  Tried this round to
@@ -49,7 +52,7 @@ __device__ __forceinline__ double lean_div5(double a, double b) {
 }
 // a / b for code that cannot re-run itself (user models, user_model.hip: smc_div): the six-operation division, and the
 // compiler's IEEE sequence whenever that did not come out finite (a divisor that is subnormal or whose reciprocal is, an
-// overflowing a * (1 / b), 0 / 0, ...).  Equal to a / b bit for bit unless |b| >= 2^1021 (the reciprocal is subnormal and
+// overflowing a * (1 / b), 0 / 0, ...).  Equal to a / b (up to lean_div6's one pair in 2^44) unless |b| >= 2^1021 (the reciprocal is subnormal and
 // loses bits) or the quotient itself is subnormal (last bits).  On wave-uniform operands the test is one v_cmp_class and one
 // scalar branch; the IEEE sequence costs ten more instructions and twice the latency on the serial chain of a stiff solve.
 __device__ __forceinline__ double checked_lean_div(double a, double b) {
