@@ -542,7 +542,10 @@ def main():
         ach_tflops = flop_per_launch / (solve_ms * 1e-3) / 1e12
         hbm_gbps = HBM_BYTES_PER_PARTICLE_SOLVE * n_local / (solve_ms * 1e-3) / 1e9
         ess_ms = timing["ess"]["ms"]
-        traffic, traffic_note = measured_traffic("void smc::mm_solve_kernel<false, false>", n_local)
+        # the instantiation a sweep of this size launches (csrc/mm_kernels.hip: kFastTailMaxParticles): <WRITE_PRED, EXACT, FAST>
+        fast = (not args.no_fast_tail) and n_local <= 4_000_000
+        kernel_name = "mm_solve_kernel<false, false, %s>" % ("true" if fast else "false")
+        traffic, traffic_note = measured_traffic("void smc::" + kernel_name, n_local)
         valu, valu_note = measured_valu_issue(n_local)
         ess_l = timing["ess"]["launches"]
         ess_avg_ms = ess_ms / max(1, ess_l)
@@ -566,7 +569,7 @@ def main():
             "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(),
             "kernel_ms": {k: v for k, v in timing.items()},
             "steady_state": steady,
-            "roofline": {"kernel": "mm_solve_kernel<false, false> (persistent RK45 solve, lane-level dynamic scheduling: csrc/solve_sched.h)",
+            "roofline": {"kernel": kernel_name + " (persistent RK45 solve, lane-level dynamic scheduling: csrc/solve_sched.h; lone chains: hand-written loop of csrc/mm_rk45.h)",
                          "bound": "mfma",
                          "bound_note": "compute roof: the kernel issues FP64 vector FMAs (no contraction larger than 3x3, so "
                                        "MFMA is unused); on MI355X the FP64 matrix and vector peaks coincide (78.6 TFLOP/s), "

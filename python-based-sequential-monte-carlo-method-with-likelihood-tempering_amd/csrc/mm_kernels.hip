@@ -200,7 +200,6 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     int64_t stiff_cap;
     unsigned solo_cap;
     int patience;               // solve_sched.h: attempts a wave waits for all its lanes before a hand-out (homogeneous sweeps)
-    int fast_tail;              // lone chains run the hand-written attempt loop (mm_rk45.h: mm_fast_uniform_attempts; smc_set_fast_tail)
 };
 
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
@@ -263,7 +262,10 @@ __device__ __forceinline__ bool mm_certainly_rejected(const MMModel &mm, const S
 
 // What solve_sched.h needs to know about a Michaelis-Menten item (see the list at the top of that file).
 // EXACT: parity mode (smc_set_exact_pow) - the step controller's power is the correctly rounded pow(x, -0.2), mm_rk45.h.
-template <bool WRITE_PRED, bool EXACT>
+// FAST: lone chains run the hand-written attempt loop (mm_rk45.h: mm_fast_uniform_attempts).  A template parameter, not a flag:
+// the block's registers cost the kernel its fourth wave per SIMD (140 instead of 128 VGPRs), which a sweep over 10^6 particles
+// does not notice but one over 10^7 does (steady state +7 %), so launch_solve picks the instantiation by the size of the sweep.
+template <bool WRITE_PRED, bool EXACT, bool FAST>
 struct MMOps {
     struct Item {
         MMItem s;
@@ -353,7 +355,7 @@ struct MMOps {
     // where it pays - the next data time at least four steps away (an attempt that turns out to need an output is computed
     // twice) - and never in parity mode (its arithmetic is the default mode's).
     __device__ __forceinline__ int uniform_attempts(Item &it, int budget) const {
-        if (EXACT || !a.fast_tail) return uniform_attempts_plain(*this, it, budget);
+        if (EXACT || !FAST) return uniform_attempts_plain(*this, it, budget);
         int st = 0;
         do {
             SMC_ISA_MARK("uniform_tail_attempt");
@@ -414,7 +416,7 @@ struct MMOps {
 #else
 #define SMC_SOLVE_WAVES_ATTR
 #endif
-template <bool WRITE_PRED, bool EXACT>
+template <bool WRITE_PRED, bool EXACT, bool FAST>
 __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_kernel(MMModel mm, SolveArgs a) {
     extern __shared__ double2 smem_tp[];
     const int n_ex = mm.n_ex, n_t = mm.n_t;
@@ -428,7 +430,7 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[0]) : 0u;
     unsigned n_solo = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[1]) : 0u;
     if (n_solo > a.solo_cap) n_solo = a.solo_cap;   // the overflow went onto the ordinary list (stiff_list_append)
-    MMOps<WRITE_PRED, EXACT> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff,
+    MMOps<WRITE_PRED, EXACT, FAST> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff,
                                  a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, mm.rtol, mm.atol, a.patience};
     solve_persistent(ops, a.queue, s_pool);
 }
@@ -580,12 +582,21 @@ static size_t solve_lds_bytes(int n_ex, int n_t) {
 // Persistent grid of a sweep over n particles: enough blocks to fill every CU at the kernel's occupancy; for a small
 // population as many as its chunks need plus one wave per item, so that every solo solve finds a wave of its own (blocks
 // beyond the work find the queue empty and leave at once).
+// Up to this many particles per sweep the lone chains run the hand-written loop (the FAST instantiations).  Whole runs on one
+// GPU: 10^6 particles 86.3 -> 76.7 ms with it, 10^7 particles 430 -> 440 ms, 10^8 3.48 -> 3.69 s (profiles/r03_ab_fast_tail.log):
+// the chains do not grow with the population, the bulk that pays for the lost wave does.
+#ifndef SMC_FAST_TAIL_MAX
+#define SMC_FAST_TAIL_MAX 4000000
+#endif
+constexpr int64_t kFastTailMaxParticles = SMC_FAST_TAIL_MAX;
+static bool use_fast_tail(const smc_ctx *ctx, int64_t n) { return ctx->fast_tail != 0 && ctx->exact_pow == 0 && n <= kFastTailMaxParticles; }
+
 static int64_t solve_grid_blocks(const smc_ctx *ctx, int64_t n) {
     const int64_t waves_per_block = kSolveBlock / kWave;
     const int64_t items = ((n + kWave - 1) / kWave) * kWave * ctx->mm.n_ex;
     const int64_t chunks = (items + kChunk - 1) / kChunk;
     const int64_t need = (chunks + waves_per_block - 1) / waves_per_block + (n * ctx->mm.n_ex + waves_per_block - 1) / waves_per_block;
-    int64_t blocks = (int64_t)ctx->cu_count * ctx->solve_blocks_per_cu;
+    int64_t blocks = (int64_t)ctx->cu_count * (use_fast_tail(ctx, n) ? ctx->solve_blocks_per_cu_fast : ctx->solve_blocks_per_cu);
     if (blocks > need) blocks = need;
     return blocks < 1 ? 1 : blocks;
 }
@@ -621,18 +632,20 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.stiff_cap = sl.cap;
     a.solo_cap = sl.solo_cap;
     a.patience = patience;
-    a.fast_tail = ctx->fast_tail;
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
     const bool exact = ctx->exact_pow != 0;
-    void (*kern)(MMModel, SolveArgs) = pred ? (exact ? mm_solve_kernel<true, true> : mm_solve_kernel<true, false>)
-                                            : (exact ? mm_solve_kernel<false, true> : mm_solve_kernel<false, false>);
+    const bool fast = use_fast_tail(ctx, n);
+    void (*kern)(MMModel, SolveArgs) =
+        pred ? (exact ? mm_solve_kernel<true, true, false> : fast ? mm_solve_kernel<true, false, true> : mm_solve_kernel<true, false, false>)
+             : (exact ? mm_solve_kernel<false, true, false> : fast ? mm_solve_kernel<false, false, true> : mm_solve_kernel<false, false, false>);
     if (lds > 48 * 1024 && !ctx->solve_lds_raised) {
         // the largest data set (16 x 256) needs 66 + 30 KB of the CU's 160 KB: above the default dynamic limit.  The
         // attribute belongs to the (function, device) pair, so the flag lives in the context, not in the process.
         hipError_t e = hipSuccess;
-        for (const void *f : {reinterpret_cast<const void *>(&mm_solve_kernel<true, true>), reinterpret_cast<const void *>(&mm_solve_kernel<true, false>),
-                              reinterpret_cast<const void *>(&mm_solve_kernel<false, true>), reinterpret_cast<const void *>(&mm_solve_kernel<false, false>)})
+        for (const void *f : {reinterpret_cast<const void *>(&mm_solve_kernel<true, true, false>), reinterpret_cast<const void *>(&mm_solve_kernel<true, false, false>),
+                              reinterpret_cast<const void *>(&mm_solve_kernel<true, false, true>), reinterpret_cast<const void *>(&mm_solve_kernel<false, true, false>),
+                              reinterpret_cast<const void *>(&mm_solve_kernel<false, false, false>), reinterpret_cast<const void *>(&mm_solve_kernel<false, false, true>)})
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) {
             smc_fail(ctx, "mm_solve_kernel: raising the dynamic LDS limit failed (hipFuncSetAttribute)");
@@ -686,13 +699,15 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
                        ctx->d_counters, dbg ? ctx->dbg_lk2 : nullptr, dbg ? ctx->dbg_r : nullptr);
 }
 
-int query_solve_blocks_per_cu() {
+int query_solve_blocks_per_cu(bool fast) {
     if (const char *e = getenv("SMC_SOLVE_BLOCKS_PER_CU")) {   // experiments: persistent blocks (4 waves each) per CU
         const int v = atoi(e);
         if (v >= 1) return v < 16 ? v : 16;     // beyond the hardware's wave slots the extra blocks only queue up
     }
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false, false>, kSolveBlock, solve_lds_bytes(6, 40)) != hipSuccess || nb < 1)
+    const hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false, false, true>, kSolveBlock, solve_lds_bytes(6, 40))
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, mm_solve_kernel<false, false, false>, kSolveBlock, solve_lds_bytes(6, 40));
+    if (e != hipSuccess || nb < 1)
         nb = 2;
     return nb;
 }

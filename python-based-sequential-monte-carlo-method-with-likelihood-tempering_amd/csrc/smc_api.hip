@@ -145,7 +145,8 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, device));
         c->cu_count = prop.multiProcessorCount;
-        c->solve_blocks_per_cu = query_solve_blocks_per_cu();
+        c->solve_blocks_per_cu = query_solve_blocks_per_cu(false);
+        c->solve_blocks_per_cu_fast = query_solve_blocks_per_cu(true);
     }
     CK(hipHostMalloc(&c->h_counters, sizeof(SweepCounters)));
     CK(hipMalloc(&c->d_noise, nb * (dim + 1)));

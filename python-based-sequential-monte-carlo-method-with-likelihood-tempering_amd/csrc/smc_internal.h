@@ -178,7 +178,7 @@ struct smc_ctx {
     int64_t last_sweep_items = 0, last_sweep_long_items = 0, pending_sweep_items = 0;   // of the last finished MM Metropolis sweep
     int exact_pow = 0;                     // parity mode: correctly rounded pow(x, -0.2) in the step controller (smc_set_exact_pow)
     bool solve_lds_raised = false;         // hipFuncAttributeMaxDynamicSharedMemorySize raised on THIS device
-    int cu_count = 0, solve_blocks_per_cu = 0;
+    int cu_count = 0, solve_blocks_per_cu = 0, solve_blocks_per_cu_fast = 0;   // persistent blocks per CU of the two kinds of mm_solve_kernel
     // debug capture of the last MH iteration (lk2, accept flags; proposals live in SMC_SET_PRED)
     int debug_capture = 0;
     double *dbg_lk2 = nullptr;
@@ -211,7 +211,7 @@ namespace smc {
 // kernel launchers implemented in mm_kernels.hip
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred);
 void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);   // mh.moment_rows set: returns the row count in ctx->moment_rows_n
-int query_solve_blocks_per_cu();
+int query_solve_blocks_per_cu(bool fast);
 // implemented in meth_smc.hip
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);
 void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);

@@ -79,6 +79,11 @@ def test_k8_loop_control_is_wave_uniform(src, kernel, tmp_path):
     shutil.rmtree(tmp_path, ignore_errors=True)
 
 
+# <WRITE_PRED, EXACT, FAST> as mm_kernels.hip launches them: FAST (the hand-written lone-chain loop) only in the default mode
+MM_SOLVE_INSTANTIATIONS = ("mm_solve_kernelILb0ELb0ELb0", "mm_solve_kernelILb0ELb0ELb1", "mm_solve_kernelILb0ELb1ELb0",
+                           "mm_solve_kernelILb1ELb0ELb0", "mm_solve_kernelILb1ELb0ELb1", "mm_solve_kernelILb1ELb1ELb0")
+
+
 def _load_tool(name):
     import importlib.util
     spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
@@ -101,7 +106,7 @@ def test_mm_solve_kernel_has_no_cross_lane_operation_in_a_loop_that_lanes_leave_
     divergent and compiled the 'uniform' attempt loop with exec-mask control flow (tools/uniformity_report.py)."""
     U = _load_tool("uniformity_report")
     ll, uni = U.compile_ir(os.path.join(CSRC, "mm_kernels.hip"), str(tmp_path))
-    for inst in ("mm_solve_kernelILb0ELb0", "mm_solve_kernelILb0ELb1", "mm_solve_kernelILb1ELb0", "mm_solve_kernelILb1ELb1"):
+    for inst in MM_SOLVE_INSTANTIATIONS:
         name, cycles, n_div = U.kernel_cycles(ll, uni, inst)
         assert n_div > 0                                   # the per-lane branches are there: the parser saw the kernel
         bad = [(c["depth"], len(c["blocks"]), c["cross_lane"][:3]) for c in cycles if c["cross_lane"]]
@@ -134,7 +139,7 @@ def test_mm_chunk_dequeue_in_the_isa(tmp_path):
     subprocess.run([HIPCC, *FLAGS, "-DSMC_ISA_MARKS", "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, "mm_kernels.hip")],
                    check=True, stderr=subprocess.DEVNULL, timeout=600)
     lines = open(asm).read().split("\n")
-    for inst in ("mm_solve_kernelILb0ELb0", "mm_solve_kernelILb0ELb1", "mm_solve_kernelILb1ELb0", "mm_solve_kernelILb1ELb1"):
+    for inst in MM_SOLVE_INSTANTIATIONS:
         start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3smc15" + inst + r"\w*:", l))
         end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
         body = [l.strip() for l in lines[start:end]]
@@ -150,9 +155,9 @@ def test_mm_chunk_dequeue_in_the_isa(tmp_path):
             loop = [l for l in body[lab:back + 1] if l and not l.startswith(";")]
             assert not [l for l in loop if re.match(r"s_\w+_saveexec", l)], f"{inst}: exec-mask control flow in the uniform attempt loop"
             assert sum(1 for l in loop if l.startswith("s_cbranch_vcc")) >= 4
-        # the hand-written block is there (default mode only) and is a loop of scalar branches
+        # the hand-written block is there (FAST instantiations only) and is a loop of scalar branches
         fast = [i for i, l in enumerate(body) if re.match(r"^\.Lfast_loop_\d+:", l)]
-        assert len(fast) == (0 if inst.endswith("ELb1") else 2), (inst, fast)     # solo phase + uniform tail
+        assert len(fast) == (2 if inst.endswith("ELb1") else 0), (inst, fast)     # FAST: solo phase + uniform tail
         for f0 in fast:
             f1 = next(i for i in range(f0, len(body)) if re.match(r"^\.Lfast_end_\d+:", body[i]))
             blk = [l for l in body[f0:f1] if l and not l.startswith(";") and not l.startswith(".")]
