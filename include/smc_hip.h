@@ -162,7 +162,7 @@ int smc_set_early_reject(smc_ctx *ctx, int enable);
 /* Michaelis-Menten sweeps hand the predictably long solves (Vmax > 60 Km: RK45 runs on its stability limit for ~3.7 Vmax/Km
  * attempts) out BEFORE the index-ordered items (default: on), so that the serial chains that bound a sweep start at its
  * beginning, and run the stiffest of them (Vmax > 1000 Km, at most one solve per wave of the sweep's grid) SOLO: one wave per solve on
- * wave-uniform operands from the first attempt (0.43 instead of ~0.55 us per attempt while the rest of the population
+ * wave-uniform operands from the first attempt (0.33 - smc_set_fast_tail - instead of ~0.55 us per attempt while the rest of the population
  * keeps the other lanes busy).  The order in which independent (particle, experiment) solves run - and the lane count they
  * run on - changes no result: the reference's one-Ray-task-per-particle fan-out (Micmem_likelihood.py:83-87) leaves it to its
  * scheduler too; 0 restores round 2's plain index order (A/B timing, tests).  Methanation: the same switch selects the
