@@ -448,6 +448,8 @@ def main():
                     help="A/B switch: hand the (particle, experiment) solves out in plain index order (SMCSettings.stiff_first)")
     ap.add_argument("--no-in-phase", action="store_true",
                     help="A/B switch: never let a wave wait for all of its lanes before a hand-out (SMCSettings.in_phase)")
+    ap.add_argument("--no-cost-order", action="store_true",
+                    help="A/B switch: heterogeneous Metropolis sweeps hand their solves out in index order (SMCSettings.cost_order)")
     ap.add_argument("--no-fast-tail", action="store_true",
                     help="A/B switch: lone chains run the compiled step function, not the hand-written loop (smc_set_fast_tail)")
     ap.add_argument("--progress", action="store_true",
@@ -469,7 +471,8 @@ def main():
     n_local = args.particles_per_gpu
     n_global = n_local * world
     t, P_obs, S0 = load_mm_data()
-    s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first, in_phase=not args.no_in_phase)
+    s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first, in_phase=not args.no_in_phase,
+                        cost_order=not args.no_cost_order)
 
     # SMC_BENCH_DEVICE pins every rank to one device (rehearsing the multi-rank path on a one-GPU box)
     dev = int(os.environ.get("SMC_BENCH_DEVICE", local_rank))

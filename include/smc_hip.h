@@ -168,6 +168,11 @@ int smc_set_early_reject(smc_ctx *ctx, int enable);
  * scheduler too; 0 restores round 2's plain index order (A/B timing, tests).  Methanation: the same switch selects the
  * misfit order of the experiments in the early-rejection sweeps (smc_meth_sweep_check). */
 int smc_set_stiff_first(smc_ctx *ctx, int enable);
+/* Michaelis-Menten Metropolis sweeps over a heterogeneous population hand their index-ordered solves out by cost class
+ * (Vmax / Km of the proposal, four classes per octave, counting sort on the device) and in phase, so that the 64 solves a wave
+ * starts together are alike: same results (the order of independent solves is free, as for smc_set_stiff_first), 20-25 % less
+ * time for the sweeps of the middle of a run.  Default: on; needs smc_set_in_phase on.  0: A/B timing, tests. */
+int smc_set_cost_order(smc_ctx *ctx, int enable);
 /* A Michaelis-Menten solve that runs alone in its wave (a solo solve, the last survivor of a sweep) performs the attempts that
  * neither produce an output nor meet a special case in a hand-written instruction sequence (csrc/mm_rk45.h:
  * mm_fast_uniform_attempts: ~140 instead of ~190 instructions per attempt, the Dormand-Prince tableau resident in scalar
@@ -341,6 +346,9 @@ int smc_comm_barrier(smc_ctx *ctx);
  * the send staging, an ncclSend/ncclRecv pair addressed to this rank itself and the receive staging into rows
  * [dst_row, dst_row+cnt) of the FILT set (theta and lk) - step 3 of smc_resample_phase3 for a self-addressed block.
  * Needs a communicator (smc_comm_init with SMC_FORCE_RCCL=1 on one rank). */
+/* Probes (tools/sort_probe.py): every Michaelis-Menten likelihood sweep hands its index-ordered items out in the uploaded order
+ * (a permutation of 0 .. n-1: position -> particle) with the given in-phase patience; order == NULL switches it off. */
+int smc_debug_set_order(smc_ctx *ctx, const int32_t *order, int64_t n, int patience);
 int smc_debug_rccl_self_exchange(smc_ctx *ctx, int64_t row, int64_t cnt, int64_t dst_row);
 /* Loopback rehearsal of the multi-rank path on ONE device: `peers` are the `world` contexts of one process
  * (peers[rank] == ctx), typically one host thread per rank.  smc_resample_phase3 then only packs (gathers own

@@ -57,6 +57,7 @@ SIGNATURES = {
     "smc_set_resampling": (cint, [c_ctx, cint]),
     "smc_set_early_reject": (cint, [c_ctx, cint]),
     "smc_set_stiff_first": (cint, [c_ctx, cint]),
+    "smc_set_cost_order": (cint, [c_ctx, cint]),
     "smc_set_fast_tail": (cint, [c_ctx, cint]),
     "smc_set_in_phase": (cint, [c_ctx, cint]),
     "smc_set_exact_pow": (cint, [c_ctx, cint]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "smc_download_lk": (cint, [c_ctx, cint, c_dp, i64]),
     "smc_download_accept_flags": (cint, [c_ctx, c_u8p, i64]),
     "smc_download_item_info": (cint, [c_ctx, ctypes.POINTER(ctypes.c_int32), i64]),
+    "smc_debug_set_order": (cint, [c_ctx, ctypes.POINTER(ctypes.c_int32), i64, cint]),
     "smc_commit_filt_to_pred": (cint, [c_ctx]),
     "smc_sample_prior_device": (cint, [c_ctx, u64, i64]),
     "smc_loglik": (cint, [c_ctx, cint, c_i64p, c_i64p]),

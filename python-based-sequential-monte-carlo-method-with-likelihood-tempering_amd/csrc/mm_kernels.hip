@@ -92,6 +92,62 @@ __device__ __forceinline__ void stiff_list_append(const StiffList &sl, int64_t p
     }
     sl.particles[atomicAdd(sl.count, 1u)] = (int32_t)p;
 }
+// ---------------------------------------------------------------------------------------------
+// Cost order of a Metropolis sweep.  What a wave loses in a heterogeneous population is lanes (SQ counters on the proposals of
+// a mid-run sweep: vector ALUs 86 % busy as ever, 59 % of the lanes active against 77-82 % in the posterior phase): an item
+// of ~8 attempts still owes its 40 outputs, the output loop of a wave runs as long as the lane that has just taken the longest
+// step needs, and unlike neighbours are never in phase.  The number of attempts of a solve is very nearly a function of
+// Vmax / Km, so the proposals are binned by it - four classes per octave, descending, out-of-support proposals last - with a
+// counting sort on the device (propose kernel: class byte; histogram per block of the same 256 contiguous slices, one block
+// turns the table into offsets, scatter), and the index-ordered pass of the solve kernel hands out position -> order[position]:
+// the 64 items a wave starts together are alike and - with the in-phase patience, which a wave drops as soon as one of its
+// lanes holds a straggler (solve_sched.h: long_running) - stay in phase.  Proposals of sweep 12 of a 10^6-particle run
+// (tools/sort_probe.py): 1.340 ms in the run's order, 1.178 physically sorted, 1.193 through order[], 1.008 with patience 12.
+// The order of independent solves changes no result; the order inside a class depends on atomics and need not repeat.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCostBuckets = 128, kCostBlocks = 256;
+__device__ __forceinline__ unsigned mm_cost_bucket(double Vmax, double Km, bool in_support) {
+    if (!in_support || !(Km > 0.0)) return kCostBuckets - 1;
+    // exponent and two mantissa bits of the single-precision ratio: four classes per octave between 2^-12 and 2^19
+    const int u = (int)(__float_as_uint((float)(Vmax / Km)) >> 21) - (127 - 12) * 4;
+    const int k = u < 0 ? 0 : (u > 123 ? 123 : u);
+    return (unsigned)(123 - k);         // long solves first
+}
+__global__ void __launch_bounds__(256) cost_hist_kernel(const uint8_t *__restrict__ bucket, int64_t n, unsigned *__restrict__ table) {
+    __shared__ unsigned h[kCostBuckets];
+    if (threadIdx.x < kCostBuckets) h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t per = (n + kCostBlocks - 1) / kCostBlocks, lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[bucket[i]], 1u);
+    __syncthreads();
+    if (threadIdx.x < kCostBuckets) table[(int64_t)blockIdx.x * kCostBuckets + threadIdx.x] = h[threadIdx.x];
+}
+// one block of kCostBuckets threads: table[b][k] <- first position of block b's members of class k
+__global__ void __launch_bounds__(kCostBuckets) cost_offsets_kernel(unsigned *__restrict__ table) {
+    __shared__ unsigned total[kCostBuckets];
+    const int k = threadIdx.x;
+    unsigned run = 0;
+    for (int b = 0; b < kCostBlocks; ++b) {
+        const unsigned v = table[b * kCostBuckets + k];
+        table[b * kCostBuckets + k] = run;
+        run += v;
+    }
+    total[k] = run;
+    __syncthreads();
+    unsigned base = 0;
+    for (int j = 0; j < k; ++j) base += total[j];
+    table[kCostBlocks * kCostBuckets + k] = base;
+}
+__global__ void __launch_bounds__(256) cost_scatter_kernel(const uint8_t *__restrict__ bucket, int64_t n, const unsigned *__restrict__ table,
+                                                          int32_t *__restrict__ order) {
+    __shared__ unsigned cur[kCostBuckets];
+    if (threadIdx.x < kCostBuckets)
+        cur[threadIdx.x] = table[(int64_t)blockIdx.x * kCostBuckets + threadIdx.x] + table[kCostBlocks * kCostBuckets + threadIdx.x];
+    __syncthreads();
+    const int64_t per = (n + kCostBlocks - 1) / kCostBlocks, lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&cur[bucket[i]], 1u)] = (int32_t)i;
+}
+
 __global__ void __launch_bounds__(256)
 mm_stiff_scan_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, StiffList sl) {
     if (blockIdx.x == 0 && threadIdx.x < 2) sl.count_next[threadIdx.x] = 0u;
@@ -126,8 +182,6 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
     }
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    if (mh.pending_sums)   // early rejection reads the siblings' results: none of this sweep's items has finished yet
-        for (int k = 0; k < mh.pending_n_ex; ++k) mh.pending_sums[(int64_t)k * n + p] = __longlong_as_double(0x7ff8000000000000LL);
     const double f0 = filt[p], f1 = filt[stride + p], f2 = filt[2 * stride + p];
     double z0, z1, z2;
     if (mh.device_rng) {
@@ -170,6 +224,19 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
     prop[pstride + p] = w1;
     prop[2 * pstride + p] = __dadd_rn(__dmul_rn(c2, p0), __dmul_rn(f2, q0));
     p0_out[p] = (uint8_t)(p0 != 0.0);
+    if (mh.cost_bucket) mh.cost_bucket[p] = (uint8_t)mm_cost_bucket(w0, w1, p0 != 0.0);
+    // early rejection reads the siblings' results: none of this sweep's items has finished yet (NaN).  In a cost-ordered sweep
+    // the solve kernel never sees an out-of-support proposal: its items are published here (sum 0, no attempts)
+    const bool done_here = mh.cost_bucket && p0 == 0.0;
+    if (mh.pending_sums || done_here)
+        for (int k = 0; k < mh.pending_n_ex; ++k) {
+            if (done_here) {
+                mh.done_sums[(int64_t)k * n + p] = 0.0;
+                mh.done_info[(int64_t)k * n + p] = 0;
+            } else {
+                mh.pending_sums[(int64_t)k * n + p] = __longlong_as_double(0x7ff8000000000000LL);
+            }
+        }
     // a proposal inside the support whose solves will be long: onto the list of this sweep (the solve kernel applies the
     // same predicate to the same stored values when it skips the particle in its index-ordered pass)
     if (mh.stiff.particles && p0 != 0.0 && mm_is_stiff(w0, w1)) stiff_list_append(mh.stiff, p, w0, w1);
@@ -200,7 +267,9 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     int64_t stiff_cap;
     unsigned solo_cap;
     int patience;               // solve_sched.h: attempts a wave waits for all its lanes before a hand-out (homogeneous sweeps)
-};
+    const int32_t *order;       // cost order of the sweep: position of the index-ordered pass -> particle (nullptr: identity)
+    const unsigned *n_ordered;  // ... and how many positions it has: the in-support proposals (the others were published by the
+};                              // propose kernel and come last in `order`)
 
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
 // both evaluate the same floating-point expression
@@ -285,11 +354,13 @@ struct MMOps {
     unsigned n_solo;
     double rtol, atol;
     int patience;
+    long long n_pos;            // positions of the index-ordered pass
 
     __device__ __forceinline__ int start(long long p, int e, bool from_list, Item &nb) const {
         nb.out_idx = (int64_t)e * a.n + p;
         nb.pred = nullptr;
-        const bool masked = a.p0 && a.p0[p] == 0;        // masked proposal: lk2 == lk1, no solve
+        // masked proposal: lk2 == lk1, no solve (a cost-ordered sweep holds none: the propose kernel has published them)
+        const bool masked = !a.n_ordered && a.p0 && a.p0[p] == 0;
         const double Vmax = a.theta[p], Km = a.theta[a.stride + p];
         const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
         // index-ordered pass: a particle of the stiff list has been handed out already
@@ -350,6 +421,9 @@ struct MMOps {
     __device__ __forceinline__ int attempt(Item &it) const {
         return mm_item_attempt<WRITE_PRED, kDivLean6, EXACT>(it.s, s_tp, n_t, rtol, atol, it.pred);
     }
+    __device__ __forceinline__ bool long_running(const Item &it) const { return it.s.attempts > kLongItemAttempts; }
+    __device__ __forceinline__ long long positions() const { return n_pos; }
+    __device__ __forceinline__ long long particle_at(long long pos) const { return a.order ? (long long)a.order[pos] : pos; }
     // The lone chain (solve_sched.h: solo phase, uniform tail): the hand-written loop of mm_rk45.h for the attempts of a stiff
     // solve that neither produce an output nor hit a special case, mm_item_attempt for the others.  The block is entered only
     // where it pays - the next data time at least four steps away (an attempt that turns out to need an output is computed
@@ -431,7 +505,8 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     unsigned n_solo = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[1]) : 0u;
     if (n_solo > a.solo_cap) n_solo = a.solo_cap;   // the overflow went onto the ordinary list (stiff_list_append)
     MMOps<WRITE_PRED, EXACT, FAST> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff,
-                                 a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, mm.rtol, mm.atol, a.patience};
+                                 a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, mm.rtol, mm.atol, a.patience,
+                                 a.n_ordered ? (long long)__builtin_amdgcn_readfirstlane((int)a.n_ordered[0]) : (long long)a.n};
     solve_persistent(ops, a.queue, s_pool);
 }
 
@@ -615,7 +690,8 @@ static StiffList next_stiff_list(smc_ctx *ctx, int64_t n) {
 }
 
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
-                         const StiffList &sl, bool queue_cleared = false, bool reject = false, int patience = 0) {
+                         const StiffList &sl, bool queue_cleared = false, bool reject = false, int patience = 0,
+                         const int32_t *order = nullptr) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
     a.theta = theta;
@@ -632,6 +708,12 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.stiff_cap = sl.cap;
     a.solo_cap = sl.solo_cap;
     a.patience = patience;
+    a.order = order;
+    // a cost-ordered Metropolis sweep (not a probe's uploaded order): the first position of the last class = the in-support proposals
+    a.n_ordered = (order && !ctx->order_debug) ? ctx->d_order_hist + kCostBlocks * kCostBuckets + (kCostBuckets - 1) : nullptr;
+#ifdef SMC_DEBUG_PATIENCE_ENV   // A/B builds only (tools/ab_build.sh): in-phase patience of every sweep from the environment
+    if (const char *e = getenv("SMC_DEBUG_PATIENCE")) a.patience = atoi(e);
+#endif
     if (!queue_cleared) (void)hipMemsetAsync(ctx->d_queue, 0, sizeof(unsigned long long), ctx->stream);
     const size_t lds = solve_lds_bytes(mm.n_ex, mm.n_t);
     const bool exact = ctx->exact_pow != 0;
@@ -664,7 +746,8 @@ void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t
     const StiffList sl = next_stiff_list(ctx, n);
     if (sl.particles)
         hipLaunchKernelGGL(mm_stiff_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, theta, stride, n, sl);
-    launch_solve(ctx, theta, stride, n, nullptr, pred, sl);
+    launch_solve(ctx, theta, stride, n, nullptr, pred, sl, false, false, ctx->order_debug ? ctx->order_debug_patience : 0,
+                 ctx->order_debug ? ctx->d_order : nullptr);
     MHParams mh{};
     hipLaunchKernelGGL((mm_finish_kernel<0>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        theta, stride, n, ctx->d_sum_r2, ctx->d_info, nullptr, lk, nullptr, 0, nullptr, ctx->d_counters,
@@ -686,12 +769,25 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
         mh.reject_lk1 = F.lk;
     }
     mh.stiff = next_stiff_list(ctx, n);
+    // in phase (solve_sched.h) when the previous Metropolis sweep of this context had fewer than 1 long item in 20 000 ...
+    const bool homogeneous = ctx->last_sweep_items > 0 && ctx->last_sweep_long_items * 20000 < ctx->last_sweep_items;
+    // ... and otherwise, for a sweep large enough to have something to sort, in cost order (above), also in phase
+    const bool cost_order = ctx->cost_order != 0 && ctx->in_phase != 0 && !homogeneous && !ctx->order_debug && n >= 16384 &&
+                            ctx->d_order && ctx->d_bucket && ctx->d_order_hist;
+    mh.cost_bucket = cost_order ? ctx->d_bucket : nullptr;
+    mh.done_sums = ctx->d_sum_r2;
+    mh.done_info = ctx->d_info;
+    mh.pending_n_ex = ctx->mm.n_ex;
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
-    // in phase (solve_sched.h) when the previous Metropolis sweep of this context had fewer than 1 long item in 20 000
-    const int patience = (ctx->in_phase != 0 && ctx->last_sweep_items > 0 &&
-                          ctx->last_sweep_long_items * 20000 < ctx->last_sweep_items) ? kInPhasePatience : 0;
-    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.stiff, mh.zero_queue != nullptr, reject, patience);
+    if (cost_order) {
+        hipLaunchKernelGGL(cost_hist_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist);
+        hipLaunchKernelGGL(cost_offsets_kernel, dim3(1), dim3(kCostBuckets), 0, ctx->stream, ctx->d_order_hist);
+        hipLaunchKernelGGL(cost_scatter_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist, ctx->d_order);
+    }
+    const int patience = (ctx->in_phase != 0 && (homogeneous || cost_order)) ? kInPhasePatience : (ctx->order_debug ? ctx->order_debug_patience : 0);
+    launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.stiff, mh.zero_queue != nullptr, reject, patience,
+                 cost_order || ctx->order_debug ? ctx->d_order : nullptr);
     ctx->pending_sweep_items = n * ctx->mm.n_ex;
     ctx->moment_rows_n = mh.moment_rows ? (int)finish_grid(n) : 0;
     hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,

@@ -141,6 +141,9 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->d_stiff_count, 4 * sizeof(unsigned)));
     CK(hipMemsetAsync(c->d_stiff_count, 0, 4 * sizeof(unsigned), c->stream));
     CK(hipMalloc(&c->d_p0, (size_t)n_local));
+    CK(hipMalloc(&c->d_order, (size_t)n_local * sizeof(int32_t)));          // cost order of a Metropolis sweep (mm_kernels.hip)
+    CK(hipMalloc(&c->d_bucket, (size_t)n_local));
+    CK(hipMalloc(&c->d_order_hist, (size_t)(256 + 1) * 128 * sizeof(unsigned)));
     {
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, device));
@@ -216,6 +219,9 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_reject);
     (void)hipFree(c->d_stiff_count);
+    (void)hipFree(c->d_order);
+    (void)hipFree(c->d_bucket);
+    (void)hipFree(c->d_order_hist);
     (void)hipFree(c->d_stiff_list);
     (void)hipFree(c->d_mcond);
     (void)hipFree(c->d_mguess);
@@ -407,6 +413,25 @@ int smc_set_in_phase(smc_ctx *c, int enable) {
     return 0;
 }
 
+int smc_debug_set_order(smc_ctx *c, const int32_t *order, int64_t n, int patience) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    if (!order) {
+        c->order_debug = 0;
+        return 0;
+    }
+    if (n != c->n_local) return fail(c, "smc_debug_set_order: n must be the context's particle count");
+    HIPC(c, hipMemcpyAsync(c->d_order, order, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->order_debug = 1;
+    c->order_debug_patience = patience;
+    return 0;
+}
+int smc_set_cost_order(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    c->cost_order = enable != 0;
+    return 0;
+}
 int smc_set_fast_tail(smc_ctx *c, int enable) {
     if (!c) return smc_fail(nullptr, "NULL context");
     c->fast_tail = enable != 0;

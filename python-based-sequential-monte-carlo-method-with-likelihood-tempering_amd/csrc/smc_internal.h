@@ -90,6 +90,9 @@ struct MHParams {    // passed by value to the fused MH kernel
     RejectArgs *reject_out;     // nullptr: early rejection off in this sweep
     const double *reject_lk1;
     StiffList stiff;            // particles == nullptr: no list
+    uint8_t *cost_bucket;       // cost order of the sweep (mm_kernels.hip: mm_cost_bucket): one byte per proposal, or nullptr
+    double *done_sums;          // ... whose out-of-support proposals the propose kernel publishes itself ([e * n + p])
+    int *done_info;
 };
 
 struct SweepCounters {  // device-side integer counters (order-independent atomics)
@@ -172,6 +175,11 @@ struct smc_ctx {
     int32_t *d_stiff_list = nullptr;       // stiff list (item_cap entries) and its two alternating counters
     unsigned *d_stiff_count = nullptr;
     int stiff_parity = 0;
+    int32_t *d_order = nullptr;            // cost order of a sweep (n_local entries): position -> particle
+    uint8_t *d_bucket = nullptr;           // ... its cost class per proposal, and the counting sort's (blocks + 1) x buckets table
+    unsigned *d_order_hist = nullptr;
+    int cost_order = 1;                    // hand a Metropolis sweep's index-ordered items out by cost class (smc_set_cost_order)
+    int order_debug = 0, order_debug_patience = 0;   // smc_debug_set_order: every MM sweep uses the uploaded order (probes)
     int fast_tail = 1;                     // hand-written lone-chain loop in the Michaelis-Menten solve kernel (smc_set_fast_tail)
     int stiff_first = 1;                   // hand the predictably long solves out first (smc_set_stiff_first)
     int in_phase = 1;                      // let homogeneous Metropolis sweeps run their waves in phase (solve_sched.h: patience)

@@ -39,6 +39,12 @@
 //   void finish(Item &, int status)      publish the result
 //   Item broadcast(const Item &, int src)   the item of lane src in every lane (v_readlane on every field)
 //   int patience                         attempts a wave waits for ALL its lanes before a hand-out (0: none; see kRefillAt below)
+//   bool long_running(const Item &)      the item has already run long enough to count as a straggler: a wave that holds one does
+//                                        not wait (per-lane)
+//   long long positions()                positions of the index-ordered pass: n, or fewer when the sweep's order leaves out
+//                                        particles that need no solve (wave-uniform)
+//   long long particle_at(long long pos) the particle handed out at position pos (identity, or the sweep's cost order: like
+//                                        particles share a wave and stay in phase)
 //   bool reject_enabled()                wave-uniform
 //   bool certainly_rejected(const Item &)   exact bound; may read results other waves have published
 //   void cancel(Item &)                  publish "stopped: its proposal is rejected"
@@ -155,7 +161,8 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
     // Queue space: first the list, n_ex passes over it in chunks of kChunk indices of which the first kStiffPerChunk are
     // list entries (so that the chunk arithmetic stays in units of kChunk), then the index-ordered items in groups of 64
     // particles x n_ex experiments; the last group may be partial.
-    const unsigned long long n_blk = (unsigned long long)((ops.n + kWave - 1) / kWave);
+    const long long n_pos = ops.positions();
+    const unsigned long long n_blk = (unsigned long long)((n_pos + kWave - 1) / kWave);
     const unsigned n_list = ops.n_list;
     const unsigned list_cpe = (n_list + kStiffPerChunk - 1) / kStiffPerChunk;          // chunks per experiment
     const unsigned long long q_list_end = (unsigned long long)list_cpe * n_ex * kChunk;
@@ -235,6 +242,7 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
                 if (lane < take) {
                     long long p;
                     int e = q_e;
+                    bool valid = true;
                     if (q_is_list) {
                         p = ops.list[q_list + (unsigned)(q_lo % kChunk) + (unsigned)lane];
                     } else {
@@ -245,8 +253,10 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
                         for (int w = 0; w < kChunk / 64 + 1; ++w)
                             if (blk >= n_blk) { blk -= n_blk; ++e; }
                         p = (long long)blk * kWave + (long long)(item & 63);
+                        valid = p < n_pos;
+                        if (valid) p = ops.particle_at(p);
                     }
-                    if (p < ops.n) started = ops.start(p, e, q_is_list, nb) == kStartStarted;
+                    if (valid) started = ops.start(p, e, q_is_list, nb) == kStartStarted;
                 }
                 const unsigned long long started_mask = __ballot(started);
                 if (started) {
@@ -337,6 +347,8 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
             }
             idle_now = kWave - __popcll(__ballot(live));
             waited += (idle_now >= kRefillAt);                      // scalar
+            // waiting for ALL lanes makes sense only while none of them is a straggler (looked at only once the wave could hand out)
+            if (patience > 0 && idle_now >= kRefillAt && __ballot(live && ops.long_running(it)) != 0ull) waited = patience + 1;
         } while (idle_now < kRefillAt || (idle_now < kWave && waited <= patience));
     }
 }

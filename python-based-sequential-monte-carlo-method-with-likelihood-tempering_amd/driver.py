@@ -62,6 +62,7 @@ class SMCSettings:
     early_reject: bool = True         # stop a solve once its proposal is certainly rejected (exact; HipEngine.set_early_reject)
     stiff_first: bool = True          # hand the predictably long solves out first (same results; HipEngine.set_stiff_first)
     in_phase: bool = True             # homogeneous Metropolis sweeps run their waves in phase (same results; HipEngine.set_in_phase)
+    cost_order: bool = True           # heterogeneous ones hand their solves out by cost class, in phase (same results; set_cost_order)
     priors: dict = field(default_factory=lambda: {
         "Vmax": {"dist": "uniform", "low": 0, "high": 10},
         "Km": {"dist": "uniform", "low": 0, "high": 10},
@@ -326,6 +327,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         engine.set_stiff_first(s.stiff_first)
     if hasattr(engine, "set_in_phase"):
         engine.set_in_phase(s.in_phase)
+    if hasattr(engine, "set_cost_order"):
+        engine.set_cost_order(s.cost_order)
     if hasattr(engine, "set_exact_pow"):           # parity mode (the reference's NumPy stream): libm-grade step-controller power
         engine.set_exact_pow(rng == "numpy")
     start_time = time.perf_counter()

@@ -193,6 +193,12 @@ class HipEngine:
             return
         self._ck(self.L.smc_set_in_phase(self.ctx, int(bool(enable))), "smc_set_in_phase")
 
+    def set_cost_order(self, enable=True):
+        """Cost-ordered, in-phase hand-out of heterogeneous Metropolis sweeps (include/smc_hip.h: smc_set_cost_order)."""
+        if "smc_set_cost_order" in B.MISSING:      # A/B build of an earlier revision (SMC_HIP_LIB)
+            return
+        self._ck(self.L.smc_set_cost_order(self.ctx, int(bool(enable))), "smc_set_cost_order")
+
     def set_fast_tail(self, enable=True):
         """Hand-written lone-chain attempt loop of the Michaelis-Menten kernel (include/smc_hip.h: smc_set_fast_tail)."""
         if "smc_set_fast_tail" in B.MISSING:       # A/B build of an earlier revision (SMC_HIP_LIB)
@@ -237,6 +243,14 @@ class HipEngine:
         self._ck(self.L.smc_download_accept_flags(self.ctx, out.ctypes.data_as(B.c_u8p), self.n_local),
                  "smc_download_accept_flags")
         return out
+
+    def debug_set_order(self, order, patience=0):
+        """Probes: hand the index-ordered items of every MM likelihood sweep out in this order (None: off); smc_debug_set_order."""
+        if order is None:
+            self._ck(self.L.smc_debug_set_order(self.ctx, None, 0, 0), "smc_debug_set_order")
+            return
+        o = np.ascontiguousarray(order, dtype=np.int32)
+        self._ck(self.L.smc_debug_set_order(self.ctx, o.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), o.size, int(patience)), "smc_debug_set_order")
 
     def download_item_info(self, n=None):
         """(n_ex, n) records of the last Michaelis-Menten sweep: attempts | cancelled << 29 | failed << 30 (diagnostics)."""

@@ -1231,6 +1231,50 @@ def test_hand_written_lone_chain_loop_full_run_is_bit_identical(pkg, data):
     assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
 
 
+# ---------------------------------------------------------------------------------------------------
+# cost order (smc_set_cost_order): heterogeneous Metropolis sweeps hand their solves out by cost class, in phase
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [16384, 70001, 300000])
+def test_cost_ordered_handout_changes_no_result(pkg, data, n):
+    """Four fused iterations on a prior-like population (proposals from 2^-12 to beyond 2^19 in Vmax / Km: every class of the
+    counting sort, out-of-support proposals in the last one, stiff and solo lists in use) with the cost order on and off:
+    accept counts, particles and likelihoods bit-identical; and every proposal was handed out exactly once (the sweep's
+    items all carry a result: no NaN likelihood, no failure)."""
+    s = pkg.SMCSettings(n_particle=n)
+    w_cov = s.w_cov()
+    rs = np.random.RandomState(n)
+    th = rs.uniform(0.0, 10.0, (n, 3))
+    th[: n // 8, 1] = 10.0 ** rs.uniform(-5, 1, n // 8)                   # very stiff down to Vmax / Km = 1e5 ... and below 1e-3 through Vmax
+    th[n // 8: n // 4, 0] = 10.0 ** rs.uniform(-5, 1, n // 8)
+    res = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            eng.set_cost_order(on)
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            eng.loglik(pkg.SMC_SET_PRED)
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+            outs = [eng.mh_iteration_device_rng(0.01, 1.0, w_cov, 11, (3 << 16) | j, 0) for j in range(4)]
+            res[on] = ([o["accepted_now"] for o in outs], [o["n_failed"] for o in outs], eng.download_particles(pkg.SMC_SET_FILT),
+                       eng.download_lk(pkg.SMC_SET_FILT))
+    assert res[True][0] == res[False][0] and res[True][1] == res[False][1] == [0, 0, 0, 0]
+    assert np.array_equal(res[True][2], res[False][2]) and np.array_equal(res[True][3], res[False][3])
+    assert np.isfinite(res[True][3]).all()
+
+
+def test_cost_ordered_handout_full_run_is_bit_identical(pkg, data):
+    """A complete device-RNG run (early rejection on, as in the benchmark) with the cost order on and off."""
+    n = 200_000
+    runs = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n) as eng:
+            runs[on] = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n, cost_order=on), rng="device", verbose=False, seed_device=41)
+    a, b = runs[True], runs[False]
+    assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
+    assert [r_["n_accept"] for r_ in a["records"]] == [r_["n_accept"] for r_ in b["records"]]
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+
+
 @pytest.mark.parametrize("n_cand", [1, 5, 16, 17, 32])
 def test_fused_ess_search_equals_max_plus_partials(pkg, data, n_cand):
     """smc_ess_search_global (maximum + up to 32 candidates, ONE synchronisation; the ESS passes read max(lk) from device

@@ -57,7 +57,11 @@ with pkg.HipEngine(n, 3) as eng:
               "sorted by attempts": np.argsort(att, kind="stable"), "shuffled": rs.permutation(n)}
     print(f"proposals of sweep {k_want} (gamma {grabbed['gamma']:.5f}): {att.sum() / 1e6:.1f} M attempts, per particle "
           f"min {att.min()} median {int(np.median(att))} 99 % {int(np.percentile(att, 99))} max {att.max()}")
+    only = sys.argv[3] if len(sys.argv) > 3 else None         # e.g. "run order": for a counter pass over one ordering
     for name, o in orders.items():
+        if only and name != only:
+            continue
+        eng.debug_set_order(None)
         eng.upload_particles(pkg.SMC_SET_PRED, prop[o])
         eng.loglik(pkg.SMC_SET_PRED)
         eng.timing_enable(True); eng.timing_reset()
@@ -65,3 +69,15 @@ with pkg.HipEngine(n, 3) as eng:
             eng.loglik(pkg.SMC_SET_PRED)
         tm = eng.timing_get()
         print(f"  {name:22s}: solve kernel {tm['solve']['ms'] / tm['solve']['launches']:.3f} ms per sweep", flush=True)
+    # the same through the order indirection of the solve kernel (particles stay where they are; smc_debug_set_order), with patience
+    eng.upload_particles(pkg.SMC_SET_PRED, prop)
+    for name in ("sorted by Vmax / Km",):
+        for patience in (0, 12):
+            eng.debug_set_order(orders[name], patience)
+            eng.loglik(pkg.SMC_SET_PRED)
+            eng.timing_enable(True); eng.timing_reset()
+            for _ in range(5):
+                eng.loglik(pkg.SMC_SET_PRED)
+            tm = eng.timing_get()
+            print(f"  order[] = {name}, patience {patience:2d}: solve kernel {tm['solve']['ms'] / tm['solve']['launches']:.3f} ms per sweep", flush=True)
+    eng.debug_set_order(None)

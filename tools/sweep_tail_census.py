@@ -32,7 +32,7 @@ with pkg.HipEngine(n, 3) as eng:
         desc = ", ".join(f"{flat[i]}{'c' if canc.ravel()[i] else ''}@{ratio[i % n]:.0f}" for i in top)
         fin = att[canc == 0]
         print(f"sweep {k[0]:2d} gamma {gamma:.5f}: solve kernel {tm['solve']['ms']:.3f} ms, attempts {att.sum() / 1e6:6.1f} M, "
-              f"items > 256 attempts: {int((att > 256).sum())} ({int(((att > 256) & (canc == 1)).sum())} cancelled), > 1000: {int((att > 1000).sum())}, "
+              f"items > 64 attempts: {int((att > 64).sum())} of {int((att > 0).sum())} solved, > 256: {int((att > 256).sum())} ({int(((att > 256) & (canc == 1)).sum())} cancelled), > 1000: {int((att > 1000).sum())}, "
               f"longest finished {int(fin.max())}; top (attempts[c]@Vmax/Km): {desc}", flush=True)
         k[0] += 1
         return out
