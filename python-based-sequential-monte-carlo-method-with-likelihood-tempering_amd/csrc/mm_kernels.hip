@@ -106,6 +106,10 @@ __device__ __forceinline__ void stiff_list_append(const StiffList &sl, int64_t p
 // The order of independent solves changes no result; the order inside a class depends on atomics and need not repeat.
 // ---------------------------------------------------------------------------------------------
 constexpr int kCostBuckets = 128, kCostBlocks = 256;
+struct alignas(32) SortedProposal {
+    double Vmax, Km, sigma;
+    long long particle;
+};
 __device__ __forceinline__ unsigned mm_cost_bucket(double Vmax, double Km, bool in_support) {
     if (!in_support || !(Km > 0.0)) return kCostBuckets - 1;
     // exponent and two mantissa bits of the single-precision ratio: four classes per octave between 2^-12 and 2^19
@@ -138,14 +142,25 @@ __global__ void __launch_bounds__(kCostBuckets) cost_offsets_kernel(unsigned *__
     for (int j = 0; j < k; ++j) base += total[j];
     table[kCostBlocks * kCostBuckets + k] = base;
 }
+// ... and the proposals themselves (rows [c * stride + i]) into cost order, as 32-byte records (Vmax, Km, sigma, particle): one
+// scattered 32-byte write per proposal here instead of one scattered line read per value and experiment in the solve kernel
+// (whose counter traffic went from 339 to 832 MB per launch with the gathers, profiles/r03_ab_cost_order.log)
 __global__ void __launch_bounds__(256) cost_scatter_kernel(const uint8_t *__restrict__ bucket, int64_t n, const unsigned *__restrict__ table,
-                                                          int32_t *__restrict__ order) {
+                                                          const double *__restrict__ theta, int64_t stride,
+                                                          SortedProposal *__restrict__ sorted) {
     __shared__ unsigned cur[kCostBuckets];
     if (threadIdx.x < kCostBuckets)
         cur[threadIdx.x] = table[(int64_t)blockIdx.x * kCostBuckets + threadIdx.x] + table[kCostBlocks * kCostBuckets + threadIdx.x];
     __syncthreads();
     const int64_t per = (n + kCostBlocks - 1) / kCostBlocks, lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&cur[bucket[i]], 1u)] = (int32_t)i;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        SortedProposal r;
+        r.Vmax = theta[i];
+        r.Km = theta[stride + i];
+        r.sigma = theta[2 * stride + i];
+        r.particle = i;
+        sorted[atomicAdd(&cur[bucket[i]], 1u)] = r;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -269,7 +284,9 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     int patience;               // solve_sched.h: attempts a wave waits for all its lanes before a hand-out (homogeneous sweeps)
     const int32_t *order;       // cost order of the sweep: position of the index-ordered pass -> particle (nullptr: identity)
     const unsigned *n_ordered;  // ... and how many positions it has: the in-support proposals (the others were published by the
-};                              // propose kernel and come last in `order`)
+                                // propose kernel and come last in `order`); nullptr: all n (a probe's uploaded order)
+    const SortedProposal *sorted;   // with n_ordered: the proposals in cost order, one 32-byte record per position (written by the
+};                                  // counting sort's scatter): a wave's 64 starts read 2 KB in a row instead of 192 scattered lines
 
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
 // both evaluate the same floating-point expression
@@ -357,12 +374,14 @@ struct MMOps {
     long long n_pos;            // positions of the index-ordered pass
 
     __device__ __forceinline__ int start(long long p, int e, bool from_list, Item &nb) const {
-        nb.out_idx = (int64_t)e * a.n + p;
-        nb.pred = nullptr;
         // masked proposal: lk2 == lk1, no solve (a cost-ordered sweep holds none: the propose kernel has published them)
         const bool masked = !a.n_ordered && a.p0 && a.p0[p] == 0;
-        const double Vmax = a.theta[p], Km = a.theta[a.stride + p];
-        const double sigma = mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed;
+        return start_values(p, e, from_list, masked, a.theta[p], a.theta[a.stride + p], mm.est_sigma ? a.theta[2 * a.stride + p] : mm.sigma_fixed, nb);
+    }
+    __device__ __forceinline__ int start_values(long long p, int e, bool from_list, bool masked, double Vmax, double Km, double sigma,
+                                                Item &nb) const {
+        nb.out_idx = (int64_t)e * a.n + p;
+        nb.pred = nullptr;
         // index-ordered pass: a particle of the stiff list has been handed out already
         if (!from_list && list && !masked && mm_is_stiff(Vmax, Km)) return kStartSkipped;
         if (masked || sigma <= 0.0) {                    // sigma <= 0: -inf without solving (:53-54)
@@ -423,7 +442,11 @@ struct MMOps {
     }
     __device__ __forceinline__ bool long_running(const Item &it) const { return it.s.attempts > kLongItemAttempts; }
     __device__ __forceinline__ long long positions() const { return n_pos; }
-    __device__ __forceinline__ long long particle_at(long long pos) const { return a.order ? (long long)a.order[pos] : pos; }
+    __device__ __forceinline__ int start_at(long long pos, int e, Item &nb) const {
+        if (!a.n_ordered) return start(a.order ? (long long)a.order[pos] : pos, e, false, nb);   // identity, or a probe's uploaded order
+        const SortedProposal r = a.sorted[pos];
+        return start_values(r.particle, e, false, false, r.Vmax, r.Km, mm.est_sigma ? r.sigma : mm.sigma_fixed, nb);
+    }
     // The lone chain (solve_sched.h: solo phase, uniform tail): the hand-written loop of mm_rk45.h for the attempts of a stiff
     // solve that neither produce an output nor hit a special case, mm_item_attempt for the others.  The block is entered only
     // where it pays - the next data time at least four steps away (an attempt that turns out to need an output is computed
@@ -691,7 +714,7 @@ static StiffList next_stiff_list(smc_ctx *ctx, int64_t n) {
 
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
                          const StiffList &sl, bool queue_cleared = false, bool reject = false, int patience = 0,
-                         const int32_t *order = nullptr) {
+                         const int32_t *order = nullptr, bool cost_ordered = false) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
     a.theta = theta;
@@ -710,7 +733,8 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.patience = patience;
     a.order = order;
     // a cost-ordered Metropolis sweep (not a probe's uploaded order): the first position of the last class = the in-support proposals
-    a.n_ordered = (order && !ctx->order_debug) ? ctx->d_order_hist + kCostBlocks * kCostBuckets + (kCostBuckets - 1) : nullptr;
+    a.n_ordered = cost_ordered ? ctx->d_order_hist + kCostBlocks * kCostBuckets + (kCostBuckets - 1) : nullptr;
+    a.sorted = static_cast<const SortedProposal *>(ctx->d_sorted);
 #ifdef SMC_DEBUG_PATIENCE_ENV   // A/B builds only (tools/ab_build.sh): in-phase patience of every sweep from the environment
     if (const char *e = getenv("SMC_DEBUG_PATIENCE")) a.patience = atoi(e);
 #endif
@@ -773,7 +797,7 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     const bool homogeneous = ctx->last_sweep_items > 0 && ctx->last_sweep_long_items * 20000 < ctx->last_sweep_items;
     // ... and otherwise, for a sweep large enough to have something to sort, in cost order (above), also in phase
     const bool cost_order = ctx->cost_order != 0 && ctx->in_phase != 0 && !homogeneous && !ctx->order_debug && n >= 16384 &&
-                            ctx->d_order && ctx->d_bucket && ctx->d_order_hist;
+                            ctx->dim == 3 && ctx->d_order && ctx->d_bucket && ctx->d_order_hist && ctx->d_sorted;
     mh.cost_bucket = cost_order ? ctx->d_bucket : nullptr;
     mh.done_sums = ctx->d_sum_r2;
     mh.done_info = ctx->d_info;
@@ -783,11 +807,12 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     if (cost_order) {
         hipLaunchKernelGGL(cost_hist_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist);
         hipLaunchKernelGGL(cost_offsets_kernel, dim3(1), dim3(kCostBuckets), 0, ctx->stream, ctx->d_order_hist);
-        hipLaunchKernelGGL(cost_scatter_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist, ctx->d_order);
+        hipLaunchKernelGGL(cost_scatter_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist, P.theta, P.stride,
+                           static_cast<SortedProposal *>(ctx->d_sorted));
     }
     const int patience = (ctx->in_phase != 0 && (homogeneous || cost_order)) ? kInPhasePatience : (ctx->order_debug ? ctx->order_debug_patience : 0);
     launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.stiff, mh.zero_queue != nullptr, reject, patience,
-                 cost_order || ctx->order_debug ? ctx->d_order : nullptr);
+                 ctx->order_debug ? ctx->d_order : nullptr, cost_order);
     ctx->pending_sweep_items = n * ctx->mm.n_ex;
     ctx->moment_rows_n = mh.moment_rows ? (int)finish_grid(n) : 0;
     hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,

@@ -144,6 +144,7 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->d_order, (size_t)n_local * sizeof(int32_t)));          // cost order of a Metropolis sweep (mm_kernels.hip)
     CK(hipMalloc(&c->d_bucket, (size_t)n_local));
     CK(hipMalloc(&c->d_order_hist, (size_t)(256 + 1) * 128 * sizeof(unsigned)));
+    CK(hipMalloc(&c->d_sorted, (size_t)n_local * 32));
     {
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, device));
@@ -222,6 +223,7 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_order);
     (void)hipFree(c->d_bucket);
     (void)hipFree(c->d_order_hist);
+    (void)hipFree(c->d_sorted);
     (void)hipFree(c->d_stiff_list);
     (void)hipFree(c->d_mcond);
     (void)hipFree(c->d_mguess);

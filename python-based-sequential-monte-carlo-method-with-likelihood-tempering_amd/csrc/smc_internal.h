@@ -178,6 +178,7 @@ struct smc_ctx {
     int32_t *d_order = nullptr;            // cost order of a sweep (n_local entries): position -> particle
     uint8_t *d_bucket = nullptr;           // ... its cost class per proposal, and the counting sort's (blocks + 1) x buckets table
     unsigned *d_order_hist = nullptr;
+    void *d_sorted = nullptr;              // ... and the proposals in cost order (n_local 32-byte records, mm_kernels.hip: SortedProposal)
     int cost_order = 1;                    // hand a Metropolis sweep's index-ordered items out by cost class (smc_set_cost_order)
     int order_debug = 0, order_debug_patience = 0;   // smc_debug_set_order: every MM sweep uses the uploaded order (probes)
     int fast_tail = 1;                     // hand-written lone-chain loop in the Michaelis-Menten solve kernel (smc_set_fast_tail)

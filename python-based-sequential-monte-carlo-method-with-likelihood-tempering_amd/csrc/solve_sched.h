@@ -43,8 +43,9 @@
 //                                        not wait (per-lane)
 //   long long positions()                positions of the index-ordered pass: n, or fewer when the sweep's order leaves out
 //                                        particles that need no solve (wave-uniform)
-//   long long particle_at(long long pos) the particle handed out at position pos (identity, or the sweep's cost order: like
-//                                        particles share a wave and stay in phase)
+//   int start_at(long long pos, int e, Item &nb)
+//                                        start() for position pos of the index-ordered pass: particle pos, or what the sweep's
+//                                        cost order puts there (like particles share a wave and stay in phase)
 //   bool reject_enabled()                wave-uniform
 //   bool certainly_rejected(const Item &)   exact bound; may read results other waves have published
 //   void cancel(Item &)                  publish "stopped: its proposal is rejected"
@@ -240,11 +241,9 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
                 bool started = false;               // this lane's new item needs attempts: it goes into the pool
                 Item nb;
                 if (lane < take) {
-                    long long p;
                     int e = q_e;
-                    bool valid = true;
                     if (q_is_list) {
-                        p = ops.list[q_list + (unsigned)(q_lo % kChunk) + (unsigned)lane];
+                        started = ops.start(ops.list[q_list + (unsigned)(q_lo % kChunk) + (unsigned)lane], e, true, nb) == kStartStarted;
                     } else {
                         const unsigned long long item = q_lo - q_list_end + lane;
                         // 64-item group = (experiment, block of 64 particles); a chunk spans kChunk / 64 + 1 groups at most
@@ -252,11 +251,9 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
 #pragma unroll
                         for (int w = 0; w < kChunk / 64 + 1; ++w)
                             if (blk >= n_blk) { blk -= n_blk; ++e; }
-                        p = (long long)blk * kWave + (long long)(item & 63);
-                        valid = p < n_pos;
-                        if (valid) p = ops.particle_at(p);
+                        const long long pos = (long long)blk * kWave + (long long)(item & 63);
+                        if (pos < n_pos) started = ops.start_at(pos, e, nb) == kStartStarted;
                     }
-                    if (valid) started = ops.start(p, e, q_is_list, nb) == kStartStarted;
                 }
                 const unsigned long long started_mask = __ballot(started);
                 if (started) {

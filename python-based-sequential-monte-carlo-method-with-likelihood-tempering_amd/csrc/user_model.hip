@@ -382,7 +382,7 @@ struct UserOps {
     __device__ __forceinline__ int uniform_attempts(Item &it, int budget) const { return smc::uniform_attempts_plain(*this, it, budget); }
     __device__ __forceinline__ bool long_running(const Item &) const { return false; }      // patience is 0 for user models
     __device__ __forceinline__ long long positions() const { return n; }
-    __device__ __forceinline__ long long particle_at(long long pos) const { return pos; }
+    __device__ __forceinline__ int start_at(long long pos, int e, Item &nb) const { return start(pos, e, false, nb); }
     __device__ __forceinline__ void finish(Item &it, int st) const {
         publish(it.out_idx, it.s.sr2, (int)(it.attempts & 0x1fffffffu) | ((st < 0) ? (1 << 30) : 0));
     }
