@@ -401,6 +401,24 @@ def test_full_run_numpy_rng_matches_reference(pkg, data, golden_run):
     assert out["stats"]["mutation_sweeps"] == g["sweeps_theta"].shape[0] - 1
 
 
+def test_full_run_numpy_rng_at_20000_particles_matches_oracle(pkg, O, data):
+    """Parity mode with enough particles for everything the scheduler does to a sweep (stiff and solo lists, cost-ordered
+    in-phase hand-out of the heterogeneous sweeps, early rejection): a complete run on the NumPy stream against the checker's
+    run on the same stream - tempering schedule, accept counts and Metropolis lengths exact, particles and log-evidence to 1e-9."""
+    n = 20000
+    so = O.SMCSettings()
+    so.n_particle = n
+    o = O.run_smc(data, so, seed=13, n_threads=0, record_mh=False)
+    s = pkg.SMCSettings(n_particle=n, seed=13)
+    with make_engine(pkg, data, n) as eng:
+        out = pkg.run_smc(eng, s, rng="numpy", verbose=False)
+    assert [r["gamma_new"] for r in out["records"]] == [r.gamma_new for r in o["records"]]
+    assert [r["n_accept"] for r in out["records"]] == [r.n_accept for r in o["records"]]
+    assert [r["last_j"] for r in out["records"]] == [r.last_j for r in o["records"]]
+    assert abs(out["logZ"] - o["logZ"]) < 1e-9 * abs(o["logZ"])
+    assert np.abs(out["p_pred"] - o["p_pred"]).max() < 1e-9
+
+
 def test_full_run_logz_matches_oracle(pkg, O, data):
     o = O.run_smc(data, O.SMCSettings(), seed=7, n_threads=0, record_mh=False)
     s = pkg.SMCSettings(seed=7)
