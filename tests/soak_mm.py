@@ -28,6 +28,11 @@ for case in range(160):
         eng.upload_particles(pkg.SMC_SET_PRED, th)
         info2 = eng.loglik(pkg.SMC_SET_PRED)
         lk2 = eng.download_lk(pkg.SMC_SET_PRED)
+        eng.set_fast_tail(False)                      # the compiled step function instead of the hand-written lone-chain loop:
+        lk_nf, pred_nf, info_nf = eng.loglik_host(th, want_pred=(case % 3 == 0))      # the same bits, the same attempts
+        assert np.array_equal(lk, lk_nf) and info_nf["rk_attempts"] == info["rk_attempts"], ("fast tail", case, n, n_ex, n_t)
+        assert pred is None or np.array_equal(pred, pred_nf, equal_nan=True), ("fast tail, predictions", case)
+        eng.set_fast_tail(True)
         eng.set_exact_pow(True)
         eng.set_stiff_first(case % 2 == 0)
         lk_x, _, info_x = eng.loglik_host(th, want_pred=(case % 3 == 1))
