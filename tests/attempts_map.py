@@ -1,7 +1,7 @@
 """RK45 step attempts of one Michaelis-Menten solve over (Vmax, Km), by the CPU checker (and SciPy itself for a few points): the
 longest chains of a sweep sit just above Km ~ 1.5e-3, where attempts ~ 3.7 Vmax / Km; below it solve_ivp's RK45 finishes in a
 handful of steps (the first steps carry S through zero), so the longest chain of a prior population does not grow with its size.
-A test-side tool (it uses the checker): python tools/attempts_map.py"""
+Lives under tests/ because it uses the checker: python tests/attempts_map.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
