@@ -103,6 +103,8 @@ __device__ __forceinline__ void stiff_list_append(const StiffList &sl, int64_t p
 // the 64 items a wave starts together are alike and - with the in-phase patience, which a wave drops as soon as one of its
 // lanes holds a straggler (solve_sched.h: long_running) - stay in phase.  Proposals of sweep 12 of a 10^6-particle run
 // (tools/sort_probe.py): 1.340 ms in the run's order, 1.178 physically sorted, 1.193 through order[], 1.008 with patience 12.
+// (Not quite monotone: below Km ~ 1.5e-3 SciPy's RK45 - and so this kernel - finishes a solve in 5-10 steps, tests/attempts_map.py;
+// those few proposals sit in the "longest" classes and on the stiff / solo lists and simply finish at once.)
 // The order of independent solves changes no result; the order inside a class depends on atomics and need not repeat.
 // ---------------------------------------------------------------------------------------------
 constexpr int kCostBuckets = 128, kCostBlocks = 256;
