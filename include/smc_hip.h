@@ -96,7 +96,8 @@ int smc_set_model_methanation(smc_ctx *ctx, const double *cond, const double *gu
  *   __device__ double smc_user_cost(const double *theta);      rough number of RK45 step attempts of one solve with theta
  * Sweeps then hand the solves of particles above 220 attempts out before the index-ordered ones and run those above 3700
  * one per wave on wave-uniform operands (the built-in Michaelis-Menten kernel's stiff list and solo phase, smc_set_stiff_first
- * switches both off) - a sweep over a prior population is bounded by its longest serial solve, which should start first.
+ * switches both off) - a sweep over a prior population is bounded by its longest serial solve, which should start first -
+ * and heterogeneous Metropolis sweeps of 16 384 particles or more are handed out by cost class and in phase (smc_set_cost_order).
  * The hint changes the order of independent solves only, never a result; it may be crude, and NaN counts as cheap.
  * The functions may call   double smc_div(double a, double b)   for a / b: the source is compiled twice, in two namespaces
  * (so: device functions and constants only, nothing extern "C") - once with the six-operation division of the built-in

@@ -165,6 +165,27 @@ __global__ void __launch_bounds__(256) cost_scatter_kernel(const uint8_t *__rest
     }
 }
 
+// ... or, for a model the library knows nothing about (user_model.hip: the class bytes come from the model's cost hint), just the
+// particle indices: position -> particle, gathered by the solve kernel
+__global__ void __launch_bounds__(256) cost_scatter_order_kernel(const uint8_t *__restrict__ bucket, int64_t n,
+                                                                const unsigned *__restrict__ table, int32_t *__restrict__ order) {
+    __shared__ unsigned cur[kCostBuckets];
+    if (threadIdx.x < kCostBuckets)
+        cur[threadIdx.x] = table[(int64_t)blockIdx.x * kCostBuckets + threadIdx.x] + table[kCostBlocks * kCostBuckets + threadIdx.x];
+    __syncthreads();
+    const int64_t per = (n + kCostBlocks - 1) / kCostBlocks, lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&cur[bucket[i]], 1u)] = (int32_t)i;
+}
+// ctx->d_bucket (class bytes of n proposals, 127 = needs no solve) -> ctx->d_order; returns where the solve kernel finds the
+// number of positions (the first position of the last class), or nullptr when the context has no buffers for it
+const unsigned *launch_cost_sort_order(smc_ctx *ctx, int64_t n) {
+    if (!ctx->d_order || !ctx->d_bucket || !ctx->d_order_hist) return nullptr;
+    hipLaunchKernelGGL(cost_hist_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist);
+    hipLaunchKernelGGL(cost_offsets_kernel, dim3(1), dim3(kCostBuckets), 0, ctx->stream, ctx->d_order_hist);
+    hipLaunchKernelGGL(cost_scatter_order_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist, ctx->d_order);
+    return ctx->d_order_hist + kCostBlocks * kCostBuckets + (kCostBuckets - 1);
+}
+
 __global__ void __launch_bounds__(256)
 mm_stiff_scan_kernel(const double *__restrict__ theta, int64_t stride, int64_t n, StiffList sl) {
     if (blockIdx.x == 0 && threadIdx.x < 2) sl.count_next[threadIdx.x] = 0u;
@@ -267,7 +288,6 @@ constexpr int kSolveBlock = 256;   // 4 waves
 // predecessor had (almost) none runs its waves in phase (SolveArgs::patience, solve_sched.h).  A posterior-like solve takes
 // 19 +- a few attempts, the stragglers of a prior-like population hundreds to thousands.
 constexpr int kLongItemAttempts = 64;
-constexpr int kInPhasePatience = 12;
 constexpr int kPoolWords = 15;     // 8-byte words of a pooled item: 11 doubles, 2 packed int pairs, out_idx, prediction pointer
 
 struct SolveArgs {              // everything the attempt loops do not touch stays behind a pointer (RejectArgs, StiffList)

@@ -221,6 +221,9 @@ namespace smc {
 void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk, double *pred);
 void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);   // mh.moment_rows set: returns the row count in ctx->moment_rows_n
 int query_solve_blocks_per_cu(bool fast);
+// in-phase patience of homogeneous and of cost-ordered sweeps (solve_sched.h; profiles/r03_ab_patience.log, r03_ab_cost_order.log)
+constexpr int kInPhasePatience = 12;
+const unsigned *launch_cost_sort_order(smc_ctx *ctx, int64_t n);   // mm_kernels.hip: counting sort of ctx->d_bucket into ctx->d_order
 // implemented in meth_smc.hip
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);
 void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);

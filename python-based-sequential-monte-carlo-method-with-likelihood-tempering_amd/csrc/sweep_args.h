@@ -36,6 +36,10 @@ struct UserSolveArgs {
     const unsigned *stiff_count;    // [0] ordinary, [1] solo entries
     long long stiff_cap;
     unsigned solo_cap;              // solo entries the grid runs at once (one per wave); the overflow is on the ordinary list
+    // ... and, for a heterogeneous Metropolis sweep, the cost order of its in-support proposals (mm_kernels.hip: counting sort)
+    const int *order;               // position of the index-ordered pass -> particle (nullptr: identity)
+    const unsigned *n_ordered;      // how many positions it has (the out-of-support proposals were published by the scan kernel)
+    int patience;                   // solve_sched.h: in-phase waves (0: off)
 };
 
 // Arguments of smc_user_cost_scan_kernel (user_model.hip): builds the two lists and the flags of a sweep from the hint.
@@ -48,6 +52,12 @@ struct UserScanArgs {
     unsigned *count, *count_next;   // this sweep's pair of counters; the other pair is cleared for the next sweep
     long long stiff_cap;
     unsigned solo_cap;
+    // cost order of the sweep (nullptr: none): a class byte per proposal, 0 = longest ... 123 = shortest, 127 = out of support -
+    // and the items of those, which no solve kernel will see, published here (sum 0, no attempts)
+    unsigned char *bucket;
+    double *done_sums;              // [e * n + p]
+    int *done_info;
+    int n_ex;
 };
 
 }  // namespace smc

@@ -308,7 +308,8 @@ struct UserOps {
     unsigned n_list;            // a cost hint (smc_user_cost; smc_user_cost_scan_kernel below builds the lists), else nullptr / 0
     const int *solo;            // ... and its longest solves, one per wave on uniform operands
     unsigned n_solo;
-    int patience;               // in-phase waves (solve_sched.h): not used for user models
+    int patience;               // in-phase waves (solve_sched.h): with the cost order of a model that comes with a cost hint
+    long long n_pos;            // positions of the index-ordered pass
 
     __device__ __forceinline__ const double *cond(int e) const { return a.cond + (long long)e * a.n_cond; }
     const double2 *s_tp;        // the data of all experiments in LDS: rows of n_t + 1 (time, observation) pairs (item_cache_times)
@@ -380,9 +381,11 @@ struct UserOps {
         return it.s.status;
     }
     __device__ __forceinline__ int uniform_attempts(Item &it, int budget) const { return smc::uniform_attempts_plain(*this, it, budget); }
-    __device__ __forceinline__ bool long_running(const Item &) const { return false; }      // patience is 0 for user models
-    __device__ __forceinline__ long long positions() const { return n; }
-    __device__ __forceinline__ int start_at(long long pos, int e, Item &nb) const { return start(pos, e, false, nb); }
+    __device__ __forceinline__ bool long_running(const Item &it) const { return it.attempts > 64u; }
+    __device__ __forceinline__ long long positions() const { return n_pos; }
+    __device__ __forceinline__ int start_at(long long pos, int e, Item &nb) const {
+        return start(a.order ? (long long)a.order[pos] : pos, e, false, nb);
+    }
     __device__ __forceinline__ void finish(Item &it, int st) const {
         publish(it.out_idx, it.s.sr2, (int)(it.attempts & 0x1fffffffu) | ((st < 0) ? (1 << 30) : 0));
     }
@@ -471,7 +474,8 @@ extern "C" __global__ void __launch_bounds__(256) SMC_USER_WAVES_ATTR smc_user_s
     const unsigned n_list = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[0]) : 0u;
     unsigned n_solo = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[1]) : 0u;
     if (n_solo > a.solo_cap) n_solo = a.solo_cap;   // the overflow went onto the ordinary list
-    UserOps ops{a, a.n, a.n_ex, a.stiff_list, n_list, a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, 0, s_tp};
+    UserOps ops{a, a.n, a.n_ex, a.stiff_list, n_list, a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, a.patience,
+                a.n_ordered ? (long long)__builtin_amdgcn_readfirstlane((int)a.n_ordered[0]) : a.n, s_tp};
     smc::solve_persistent(ops, a.queue, s_pool);
 }
 
@@ -487,9 +491,23 @@ extern "C" __global__ void __launch_bounds__(256) smc_user_cost_scan_kernel(smc:
     double th[SMC_USER_DIM];
 #pragma unroll
     for (int c = 0; c < SMC_USER_DIM; ++c) th[c] = a.theta[c * a.stride + p];
-    const double cost = (a.p0 && a.p0[p] == 0) ? 0.0 : smc_user_ieee::smc_user_cost(th);
+    const bool masked = a.p0 && a.p0[p] == 0;
+    const double cost = masked ? 0.0 : smc_user_ieee::smc_user_cost(th);
     const bool on_list = cost > SMC_USER_LIST_COST;     // false for NaN
     a.listed[p] = on_list ? 1 : 0;
+    if (a.bucket) {      // cost class: four per factor of two in the hint, the longest first (NaN and < 1: the last real class)
+        unsigned b = 127u;
+        if (masked) {
+            for (int e = 0; e < a.n_ex; ++e) {
+                a.done_sums[(long long)e * a.n + p] = 0.0;
+                a.done_info[(long long)e * a.n + p] = 0;
+            }
+        } else {
+            const int u = (cost >= 1.0) ? (int)(__float_as_uint((float)cost) >> 21) - 127 * 4 : 0;
+            b = (unsigned)(123 - (u < 0 ? 0 : (u > 123 ? 123 : u)));
+        }
+        a.bucket[p] = (unsigned char)b;
+    }
     if (!on_list) return;
     if (cost > SMC_USER_SOLO_COST) {
         const unsigned k = atomicAdd(a.count + 1, 1u);
@@ -659,6 +677,15 @@ static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, 
         sa.count_next = u->d_count + 2 * (u->parity ^ 1);
         sa.stiff_cap = c->n_local;
         sa.solo_cap = (unsigned)(blocks * 4 / u->n_ex);      // one solo solve per wave of the grid
+        // a heterogeneous Metropolis sweep large enough to have something to sort: cost order + in-phase waves, as for the
+        // built-in model (mm_kernels.hip); the classes come from the model's hint
+        const bool cost_order = p0mask != nullptr && c->cost_order != 0 && c->in_phase != 0 && n >= 16384 && c->d_bucket;
+        if (cost_order) {
+            sa.bucket = c->d_bucket;
+            sa.done_sums = u->d_sum;
+            sa.done_info = u->d_info;
+            sa.n_ex = u->n_ex;
+        }
         void *sargs[] = {&sa};
         const hipError_t e = hipModuleLaunchKernel(u->fn_scan, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, sargs, nullptr);
         if (e != hipSuccess) {
@@ -671,6 +698,13 @@ static void launch_user_kernel(smc_ctx *c, const double *theta, int64_t stride, 
         a.stiff_count = sa.count;
         a.stiff_cap = sa.stiff_cap;
         a.solo_cap = sa.solo_cap;
+        if (cost_order) {
+            a.n_ordered = launch_cost_sort_order(c, n);
+            if (a.n_ordered) {
+                a.order = c->d_order;
+                a.patience = kInPhasePatience;
+            }
+        }
     }
     void *args[] = {&a};
     {

@@ -54,23 +54,27 @@ def test_mm_as_user_model_equals_builtin_kernel(pkg, data):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [5, 64, 3000])
+@pytest.mark.parametrize("n", [5, 64, 3000, 20000])
 def test_cost_hint_changes_the_order_of_the_solves_and_no_result(pkg, data, n):
     """smc_user_cost (include/smc_hip.h): the hinted model hands its long solves out first and runs the longest one per wave;
     likelihoods, attempt totals, and a Metropolis sweep with exact early rejection (accept flags, particles) must equal the
     plain model's bit for bit - for a grid of a few waves as for a full one.  The population reaches Vmax/Km = 5000, so both
-    lists are in use; half of the proposals leave the prior's support (masked, never listed)."""
+    lists are in use; half of the proposals leave the prior's support (masked, never listed).  From 16 384 particles on the
+    Metropolis sweeps of the hinted model are also cost-ordered and in phase (smc_set_cost_order: classes from the hint,
+    out-of-support proposals published by the scan kernel): the largest case runs that, and once more with it switched off."""
     rs = np.random.RandomState(n)
     th = np.column_stack([rs.uniform(0.5, 10, n), 10.0 ** rs.uniform(-3.3, 1, n), rs.uniform(0.01, 1, n)])
     th[0] = (9.0, 0.002, 0.5)                                              # 4500: certainly a solo solve
     out = {}
     for name, src in (("plain", pkg.user_models.MICHAELIS_MENTEN_PLAIN), ("hint", pkg.user_models.MICHAELIS_MENTEN),
-                      ("hint, lists off", pkg.user_models.MICHAELIS_MENTEN)):
+                      ("hint, lists off", pkg.user_models.MICHAELIS_MENTEN), ("hint, cost order off", pkg.user_models.MICHAELIS_MENTEN)):
         with pkg.HipEngine(n, 3, device=0) as eng:
             eng.set_prior(pkg.SMCSettings().priors)
             eng.set_model_user(src, 1, data.t, data.P_obs, cond=np.asarray(data.S0)[:, None])
-            if name.endswith("off"):
+            if name == "hint, lists off":
                 eng.set_stiff_first(False)
+            if name == "hint, cost order off":
+                eng.set_cost_order(False)
             eng.upload_particles(pkg.SMC_SET_PRED, th)
             info = eng.loglik(pkg.SMC_SET_PRED)
             lk = eng.download_lk(pkg.SMC_SET_PRED)
@@ -88,7 +92,7 @@ def test_cost_hint_changes_the_order_of_the_solves_and_no_result(pkg, data, n):
         assert np.array_equal(p0, p1) and np.array_equal(l0, l1) and mh0["accepted_now"] == mh1["accepted_now"]
         assert mh1["rk_attempts"] <= mh0["rk_attempts"]
         out[name] = (info["rk_attempts"], lk, mh0["accepted_now"], mh0["rk_attempts"], p0, l0)
-    for name in ("hint", "hint, lists off"):
+    for name in ("hint", "hint, lists off", "hint, cost order off"):
         assert out[name][0] == out["plain"][0] and out[name][2] == out["plain"][2] and out[name][3] == out["plain"][3], name
         assert np.array_equal(out[name][1], out["plain"][1]) and np.array_equal(out[name][4], out["plain"][4]), name
         assert np.array_equal(out[name][5], out["plain"][5]), name
