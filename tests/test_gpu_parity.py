@@ -1281,6 +1281,32 @@ def test_cost_ordered_handout_changes_no_result(pkg, data, n):
     assert np.isfinite(res[True][3]).all()
 
 
+def test_item_records_of_a_sweep_add_up_to_its_counters(pkg, data):
+    """smc_download_item_info (diagnostics, tools/sweep_tail_census.py): the per-(experiment, particle) records of a likelihood
+    sweep - attempts | cancelled << 29 | failed << 30 - sum to the sweep's device-counted attempts; after a Metropolis sweep in
+    cost order the records of out-of-support proposals (published by the propose kernel) are zero and cancelled solves are
+    flagged, none failed."""
+    n = 30000
+    rs = np.random.RandomState(5)
+    th = rs.uniform(0.05, 10, (n, 3))
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        info = eng.loglik(pkg.SMC_SET_PRED)
+        rec = eng.download_item_info()
+        assert rec.shape == (data.t.shape[0], n) and int((rec & 0x1fffffff).sum()) == info["rk_attempts"]
+        assert not (rec >> 29).any()
+        eng.upload_particles(pkg.SMC_SET_FILT, th)
+        eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+        out = eng.mh_iteration_device_rng(0.01, 1.0, pkg.SMCSettings(n_particle=n).w_cov(), 3, 1, 0)
+        rec = eng.download_item_info()
+        prop = eng.download_particles(pkg.SMC_SET_PRED)
+    att = rec & 0x1fffffff
+    assert int(att.sum()) == out["rk_attempts"] and not ((rec >> 30) & 1).any()
+    untouched = (prop == th).all(axis=1)                      # proposals reset to the current point: outside the prior's support
+    assert untouched.sum() > n // 10 and not att[:, untouched].any()
+    assert ((rec >> 29) & 1).sum() > 0                        # early rejection cancelled some solves of this prior-like population
+
+
 def test_cost_ordered_handout_full_run_is_bit_identical(pkg, data):
     """A complete device-RNG run (early rejection on, as in the benchmark) with the cost order on and off."""
     n = 200_000
