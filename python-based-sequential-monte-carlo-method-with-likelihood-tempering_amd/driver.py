@@ -131,7 +131,7 @@ def _ess_sums(engine, comm, max_lk, gms):
     return tot[:len(gms)], tot[len(gms):]
 
 
-def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_MAX_ESS_CAND):
+def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_MAX_ESS_CAND, hint=None):
     """main:111-144.  Candidates are evaluated `chunk` at a time by one fused pass over lk each.  With the reductions in
     the engine (one rank / RCCL) the maximum and the first 32 candidates of the grid cost ONE synchronisation
     (smc_ess_search_global): the back-off grid gamma_old + (1 - gamma_old) * 0.7^k is known in advance, the decision which
@@ -141,8 +141,10 @@ def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_
     gms, gammas, gamma_after_all = ess_candidates(gamma_old, s)
     if fused:
         # the first tempering step needs 17-18 candidates (gamma_1 ~ 2e-3 = 0.7^17), later ones sometimes more than 16: a
-        # second 24-us pass is cheaper than a second synchronisation, so every call evaluates 32
-        first = 2 * chunk
+        # second 24-us pass is cheaper than a second synchronisation, so a call evaluates 32 - unless the previous search of the
+        # run (`hint` = its iteration count) stopped well inside the first 16, as most do (11.8 on average): then one pass, and
+        # the rare search that needs more pays its second synchronisation below
+        first = chunk if (hint is not None and hint <= chunk - 4) else 2 * chunk
         max_lk, sw0, sw20 = engine.ess_search_global(gms[:first], with_max=True)
     else:
         max_lk = _max_lk(engine, comm)                                        # :116
@@ -155,7 +157,7 @@ def ess_search(engine, comm, gamma_old: float, s: SMCSettings, chunk: int = SMC_
     k0 = 0
     while k0 < len(gms):
         if fused:
-            width = 2 * chunk
+            width = first if k0 == 0 else 2 * chunk
             part = gms[k0:k0 + width]
             if k0 == 0:
                 sw, sw2 = sw0, sw20
@@ -395,7 +397,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     step = 0
     for step in range(first_step_no, s.itr_max):                                          # :109
         t_search = time.perf_counter()
-        es = ess_search(engine, comm, gamma_old, s)                           # :111-144
+        es = ess_search(engine, comm, gamma_old, s, hint=records[-1]["ess_iters"] if records else None)   # :111-144
         stats["ess_search_s"] += time.perf_counter() - t_search              # wall time of the search: max + passes + read-backs
         gamma_new, ess, max_lk = es["gamma_new"], es["ess"], es["max_lk"]
         stats["ess_iters"] += es["iters"]
