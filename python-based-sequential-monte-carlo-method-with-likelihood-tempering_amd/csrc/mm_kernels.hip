@@ -371,8 +371,9 @@ __device__ __forceinline__ bool mm_certainly_rejected(const MMModel &mm, const S
 // What solve_sched.h needs to know about a Michaelis-Menten item (see the list at the top of that file).
 // EXACT: parity mode (smc_set_exact_pow) - the step controller's power is the correctly rounded pow(x, -0.2), mm_rk45.h.
 // FAST: lone chains run the hand-written attempt loop (mm_rk45.h: mm_fast_uniform_attempts).  A template parameter, not a flag:
-// the block's registers cost the kernel its fourth wave per SIMD (140 instead of 128 VGPRs), which a sweep over 10^6 particles
-// does not notice but one over 10^7 does (steady state +7 %), so launch_solve picks the instantiation by the size of the sweep.
+// selected at run time the block's registers cost the kernel its fourth wave per SIMD (140 instead of 128 VGPRs); as its own
+// instantiation it fits into 128, but its bulk loop is still ~6 % slower than the plain one's (register allocation around the
+// block), which a sweep over 10^6 particles does not notice and one over 10^7 does: launch_solve picks by the size of the sweep.
 template <bool WRITE_PRED, bool EXACT, bool FAST>
 struct MMOps {
     struct Item {
