@@ -54,6 +54,13 @@ with pkg.HipEngine(n, 3) as eng:
                 ms.append(tm["solve"]["ms"])
             acc, att = out["accepted_now"], out["rk_attempts"]
         print(f"  {label:44s}: solve kernel {np.mean(ms):.3f} ms (min {min(ms):.3f}), accepted {acc}, attempts {att / 1e6:.1f} M", flush=True)
+    only = sys.argv[3] if len(sys.argv) > 3 else None          # "default" / "index": one variant, for a counter pass
+    if only == "default":
+        replay("cost order + in phase (default)", reps=6)
+        sys.exit(0)
+    if only == "index":
+        replay("index order, no patience", reps=6, cost=False, phase=False)
+        sys.exit(0)
     replay("index order, no patience", cost=False, phase=False)
     replay("cost order + in phase (default)")
     replay("cost order + in phase, no early rejection", reject=False)

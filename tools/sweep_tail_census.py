@@ -31,9 +31,15 @@ with pkg.HipEngine(n, 3) as eng:
         top = np.argsort(flat)[-6:][::-1]
         desc = ", ".join(f"{flat[i]}{'c' if canc.ravel()[i] else ''}@{ratio[i % n]:.0f}" for i in top)
         fin = att[canc == 0]
+        filt = eng.download_particles(pkg.SMC_SET_FILT)
+        accepted = (filt == prop).all(axis=1)                  # the selected particle is the proposal (masked ones count too)
+        longf = (att > 256) & (canc == 0)                      # long solves that ran to their end
+        lp = longf.any(axis=0)                                 # particles with such a solve
+        extra = (f"; particles with a finished solve > 256 attempts: {int(lp.sum())}, of them accepted {int((lp & accepted).sum())}"
+                 f" - attempts spent on the rejected ones {att[:, lp & ~accepted].sum() / 1e6:.2f} M")
         print(f"sweep {k[0]:2d} gamma {gamma:.5f}: solve kernel {tm['solve']['ms']:.3f} ms, attempts {att.sum() / 1e6:6.1f} M, "
               f"items > 64 attempts: {int((att > 64).sum())} of {int((att > 0).sum())} solved, > 256: {int((att > 256).sum())} ({int(((att > 256) & (canc == 1)).sum())} cancelled), > 1000: {int((att > 1000).sum())}, "
-              f"longest finished {int(fin.max())}; top (attempts[c]@Vmax/Km): {desc}", flush=True)
+              f"longest finished {int(fin.max())}{extra}; top (attempts[c]@Vmax/Km): {desc}", flush=True)
         k[0] += 1
         return out
     eng.mh_iteration_device_rng = w
