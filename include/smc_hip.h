@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 1
+#define SMC_ABI_VERSION 2    /* 2: smc_meth_sweep_check writes FIVE words (round 3 added the cancelled count); smc_mh_sweeps_device_rng */
 #define SMC_MAX_DIM 8        /* parameters per particle (3 for Michaelis-Menten, 5 for methanation) */
 #define SMC_MAX_ESS_CAND 16  /* tempering candidates evaluated by one smc_ess_partials call */
 #define SMC_MAX_RANKS 64
@@ -321,6 +321,21 @@ int smc_mh_step_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, cons
 int smc_mh_iteration_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed,
                                 uint64_t stream, int64_t global_offset, int64_t *accepted_now, int64_t *accepted_ever,
                                 int64_t *n_failed, int64_t *rk_attempts_local, double *cov_m);
+/* A BATCH of those iterations with the loop control of Micmem_SMC_main.py:243-249 on the device: n_iter (1 .. 32) iterations are
+ * enqueued back to back and the call synchronises ONCE.  After every iteration a one-block kernel takes the reference's
+ * decision on the counts summed over all ranks: `break` when r_ac.sum() > thr_stop (= r_th * n_particle, :243-246) - every
+ * kernel of the remaining iterations then returns at once - else mhstep_ratio *= 0.5 when r_ac.sum() < thr_halve
+ * (= r_threshold_min * n_particle, :247-249); a failed solve also ends the loop.  Pass the two thresholds as the doubles
+ * Python computes; counts are compared as exact doubles.  Iteration i draws with Philox stream stream0 + i and otherwise is
+ * smc_mh_iteration_device_rng's iteration, bit for bit.  Outputs: n_done iterations ran (1 <= n_done <= n_iter), stopped != 0
+ * if the loop ended by its break (or a failure) - otherwise the caller may enqueue the next batch with mhstep_ratio =
+ * ratio_next; per iteration i < n_done (arrays of n_iter entries, each optional): accepted_now/ever and n_failed (all ranks),
+ * rk_attempts_local (this rank), ratio_used (the mhstep_ratio it drew with), cov_m (n_iter x d x d, row-major).
+ * Michaelis-Menten model only (the other models' sweeps have host-side bookkeeping per sweep). */
+int smc_mh_sweeps_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed,
+                             uint64_t stream0, int n_iter, double thr_stop, double thr_halve, int64_t global_offset,
+                             int *n_done, int *stopped, double *ratio_next, int64_t *accepted_now, int64_t *accepted_ever,
+                             int64_t *n_failed, int64_t *rk_attempts_local, double *ratio_used, double *cov_m);
 /* The first half of that iteration on its own (no model needed): cov_m = np.cov(p_filt.T, bias=True) * w_cov over all ranks
  * (:212-215) and the factor sqrt(s)[:,None]*v of its SVD, both d x d row-major; either output may be NULL. */
 int smc_proposal_factor_device(smc_ctx *ctx, const double *w_cov, double *cov_m, double *transform);
@@ -343,6 +358,10 @@ int smc_comm_allgather_f64(smc_ctx *ctx, const double *in, int n, double *out /*
 int smc_comm_allgather_i64(smc_ctx *ctx, const int64_t *in, int n, int64_t *out /* world*n */);
 int smc_comm_barrier(smc_ctx *ctx);
 
+/* ---- test and probe hooks (NOT part of the drop-in surface) -------------------------------------
+ * Compiled into the library always (tests/ call them through the same C ABI), declared only when the includer asks:
+ * a reference-side binding never needs them. */
+#ifdef SMC_ENABLE_DEBUG_API
 /* One-rank rehearsal of the particle exchange with real RCCL calls: rows [row, row+cnt) of the PRED set go through
  * the send staging, an ncclSend/ncclRecv pair addressed to this rank itself and the receive staging into rows
  * [dst_row, dst_row+cnt) of the FILT set (theta and lk) - step 3 of smc_resample_phase3 for a self-addressed block.
@@ -358,6 +377,7 @@ int smc_debug_rccl_self_exchange(smc_ctx *ctx, int64_t row, int64_t cnt, int64_t
  * device) instead of the RCCL send/recv pairs.  Everything else (kernels, offsets, counts) is the RCCL path. */
 int smc_debug_set_local_peers(smc_ctx *ctx, smc_ctx **peers, int rank, int world);
 int smc_resample_phase3_pull(smc_ctx *ctx);
+#endif /* SMC_ENABLE_DEBUG_API */
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* HIP-event timing of the kernels launched on the context's stream: smc_timing_reset clears the

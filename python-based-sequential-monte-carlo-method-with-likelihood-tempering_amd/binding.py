@@ -20,6 +20,8 @@ SMC_PRIOR_MODE_MASK, SMC_PRIOR_MODE_RATIO_MASK, SMC_PRIOR_MODE_RATIO = 0, 1, 2
 PRIOR_MODES = {"mask": 0, "ratio_mask": 1, "ratio": 2}
 RESAMPLING = {"residual_systematic": 0, "systematic": 1, "multinomial": 2}
 SMC_MAX_ESS_CAND = 16
+SMC_ABI_VERSION = 2
+SMC_MH_BATCH_MAX = 32
 SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX, SMC_T_SOLVE = range(7)
 TIMING_NAMES = {SMC_T_LOGLIK: "loglik", SMC_T_MH: "mh", SMC_T_ESS: "ess", SMC_T_RESAMPLE: "resample",
                 SMC_T_MOMENTS: "moments", SMC_T_MAX: "max", SMC_T_SOLVE: "solve"}
@@ -80,6 +82,8 @@ SIGNATURES = {
     "smc_ess_search_global": (cint, [c_ctx, c_dp, cint, cint, c_dp, c_dp, c_dp]),
     "smc_resample_global": (cint, [c_ctx, f64, f64, f64, f64, cint, c_i64p, c_i64p]),
     "smc_mh_iteration_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, i64, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
+    "smc_mh_sweeps_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, cint, f64, f64, i64, c_ip, c_ip, c_dp, c_i64p, c_i64p,
+                                        c_i64p, c_i64p, c_dp, c_dp]),
     "smc_mh_iteration_last_transform": (cint, [c_ctx, c_dp]),
     "smc_proposal_factor_device": (cint, [c_ctx, c_dp, c_dp, c_dp]),
     "smc_resample_phase1": (cint, [c_ctx, f64, f64, f64, c_dp, c_i64p]),
@@ -148,8 +152,9 @@ def lib():
                 continue
             fn.restype = res
             fn.argtypes = args
-        if L.smc_abi_version() != 1:
-            raise SmcError("libsmc_hip.so ABI version mismatch")
+        ver = L.smc_abi_version()
+        if ver != SMC_ABI_VERSION and not (os.environ.get("SMC_HIP_LIB") and ver == 1):   # an A/B build of round 3 is version 1
+            raise SmcError(f"libsmc_hip.so ABI version mismatch: library {ver}, binding {SMC_ABI_VERSION}")
         _LIB = L
     return _LIB
 

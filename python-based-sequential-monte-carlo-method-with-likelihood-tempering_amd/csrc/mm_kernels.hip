@@ -113,48 +113,83 @@ struct alignas(32) SortedProposal {
     long long particle;
 };
 __device__ __forceinline__ unsigned mm_cost_bucket(double Vmax, double Km, bool in_support) {
-    if (!in_support || !(Km > 0.0)) return kCostBuckets - 1;
+    if (!in_support) return kCostBuckets - 1;     // the ONLY members of the last class: published by the propose kernel, never solved
+    // In support but with no meaningful ratio (Km <= 0 or a NaN: reachable under a normal or flat prior on Km, and in
+    // SMC_PRIOR_MODE_RATIO where every proposal counts as in support): a real class, so that the proposal gets a position in
+    // sorted[] and is solved like any other (it used to share class 127 and nobody wrote its sums).
+    if (!(Km > 0.0) || !(Vmax > 0.0)) return 0u;
     // exponent and two mantissa bits of the single-precision ratio: four classes per octave between 2^-12 and 2^19
     const int u = (int)(__float_as_uint((float)(Vmax / Km)) >> 21) - (127 - 12) * 4;
     const int k = u < 0 ? 0 : (u > 123 ? 123 : u);
     return (unsigned)(123 - k);         // long solves first
 }
+// Table of the counting sort (ctx->d_order_hist, unsigned words):  counts[kCostBlocks][kCostBuckets] - zero between sweeps: the
+// offsets kernel clears what it has read - | offs[kCostBlocks][kCostBuckets] | totals[kCostBuckets] | n_ordered.
+// A slice is a whole number of 256-particle blocks, so that every block of the propose kernel belongs to exactly one slice and
+// can add its LDS histogram to that slice's row (round 4: the separate histogram launch is gone).
+constexpr int kCostCounts = 0, kCostOffs = kCostBlocks * kCostBuckets, kCostTotals = 2 * kCostBlocks * kCostBuckets,
+              kCostNOrdered = kCostTotals + kCostBuckets, kCostTableWords = kCostNOrdered + 64;
+__host__ __device__ __forceinline__ int64_t cost_slice_blocks(int64_t n) { return (((n + 255) / 256) + kCostBlocks - 1) / kCostBlocks; }
+__host__ __device__ __forceinline__ int64_t cost_slice_particles(int64_t n) { return cost_slice_blocks(n) * 256; }
+size_t cost_table_bytes() { return (size_t)kCostTableWords * sizeof(unsigned); }
+const unsigned *cost_n_ordered(const smc_ctx *ctx) { return ctx->d_order_hist + kCostNOrdered; }
+
+// histogram of class bytes somebody else wrote (user_model.hip: the scan kernel of a model with a cost hint)
 __global__ void __launch_bounds__(256) cost_hist_kernel(const uint8_t *__restrict__ bucket, int64_t n, unsigned *__restrict__ table) {
     __shared__ unsigned h[kCostBuckets];
     if (threadIdx.x < kCostBuckets) h[threadIdx.x] = 0u;
     __syncthreads();
-    const int64_t per = (n + kCostBlocks - 1) / kCostBlocks, lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
+    const int64_t per = cost_slice_particles(n), lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
     for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) atomicAdd(&h[bucket[i]], 1u);
     __syncthreads();
-    if (threadIdx.x < kCostBuckets) table[(int64_t)blockIdx.x * kCostBuckets + threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < kCostBuckets) table[kCostCounts + (int64_t)blockIdx.x * kCostBuckets + threadIdx.x] = h[threadIdx.x];
 }
-// one block of kCostBuckets threads: table[b][k] <- first position of block b's members of class k
-__global__ void __launch_bounds__(kCostBuckets) cost_offsets_kernel(unsigned *__restrict__ table) {
-    __shared__ unsigned total[kCostBuckets];
-    const int k = threadIdx.x;
-    unsigned run = 0;
-    for (int b = 0; b < kCostBlocks; ++b) {
-        const unsigned v = table[b * kCostBuckets + k];
-        table[b * kCostBuckets + k] = run;
-        run += v;
+// one block per class, one thread per slice: offs[b][k] <- members of class k in the slices below b; totals[k]; counts <- 0
+// (round 3: one block of 128 threads walked the 256 rows one after the other, 8.5 us on the critical path of every sweep)
+__global__ void __launch_bounds__(kCostBlocks) cost_offsets_kernel(unsigned *__restrict__ table, const MHControl *__restrict__ ctl) {
+    __shared__ unsigned wsum[kCostBlocks / 64];
+    if (ctl && ctl->stop) return;      // the Metropolis loop of this batch has ended (stage_kernels.hip: mh_control_kernel)
+    const int k = blockIdx.x, b = threadIdx.x, w = b >> 6, l = b & 63;
+    const unsigned v = table[kCostCounts + b * kCostBuckets + k];
+    table[kCostCounts + b * kCostBuckets + k] = 0u;
+    unsigned inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(inc, off);
+        if (l >= off) inc += o;
     }
-    total[k] = run;
+    if (l == 63) wsum[w] = inc;
     __syncthreads();
-    unsigned base = 0;
-    for (int j = 0; j < k; ++j) base += total[j];
-    table[kCostBlocks * kCostBuckets + k] = base;
+    unsigned base = 0, tot = 0;
+    for (int q = 0; q < kCostBlocks / 64; ++q) {
+        if (q < w) base += wsum[q];
+        tot += wsum[q];
+    }
+    table[kCostOffs + b * kCostBuckets + k] = base + inc - v;
+    if (b == 0) table[kCostTotals + k] = tot;
+}
+// first position of every class from the totals (each block of a scatter kernel for itself: 128 words), then this slice's cursors
+__device__ __forceinline__ void cost_cursors(unsigned *__restrict__ table, unsigned *cur /* LDS, kCostBuckets */, unsigned *tot /* LDS */) {
+    if (threadIdx.x < kCostBuckets) tot[threadIdx.x] = table[kCostTotals + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < kCostBuckets) {
+        unsigned base = 0;
+        for (int q = 0; q < (int)threadIdx.x; ++q) base += tot[q];
+        cur[threadIdx.x] = table[kCostOffs + (int64_t)blockIdx.x * kCostBuckets + threadIdx.x] + base;
+        if (blockIdx.x == 0 && threadIdx.x == kCostBuckets - 1) table[kCostNOrdered] = base;   // positions the solve kernel hands out
+    }
+    __syncthreads();
 }
 // ... and the proposals themselves (rows [c * stride + i]) into cost order, as 32-byte records (Vmax, Km, sigma, particle): one
 // scattered 32-byte write per proposal here instead of one scattered line read per value and experiment in the solve kernel
 // (whose counter traffic went from 339 to 832 MB per launch with the gathers, profiles/r03_ab_cost_order.log)
-__global__ void __launch_bounds__(256) cost_scatter_kernel(const uint8_t *__restrict__ bucket, int64_t n, const unsigned *__restrict__ table,
+__global__ void __launch_bounds__(256) cost_scatter_kernel(const uint8_t *__restrict__ bucket, int64_t n, unsigned *__restrict__ table,
                                                           const double *__restrict__ theta, int64_t stride,
-                                                          SortedProposal *__restrict__ sorted) {
-    __shared__ unsigned cur[kCostBuckets];
-    if (threadIdx.x < kCostBuckets)
-        cur[threadIdx.x] = table[(int64_t)blockIdx.x * kCostBuckets + threadIdx.x] + table[kCostBlocks * kCostBuckets + threadIdx.x];
-    __syncthreads();
-    const int64_t per = (n + kCostBlocks - 1) / kCostBlocks, lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
+                                                          SortedProposal *__restrict__ sorted, const MHControl *__restrict__ ctl) {
+    __shared__ unsigned cur[kCostBuckets], tot[kCostBuckets];
+    if (ctl && ctl->stop) return;
+    cost_cursors(table, cur, tot);
+    const int64_t per = cost_slice_particles(n), lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
     for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         SortedProposal r;
         r.Vmax = theta[i];
@@ -168,12 +203,10 @@ __global__ void __launch_bounds__(256) cost_scatter_kernel(const uint8_t *__rest
 // ... or, for a model the library knows nothing about (user_model.hip: the class bytes come from the model's cost hint), just the
 // particle indices: position -> particle, gathered by the solve kernel
 __global__ void __launch_bounds__(256) cost_scatter_order_kernel(const uint8_t *__restrict__ bucket, int64_t n,
-                                                                const unsigned *__restrict__ table, int32_t *__restrict__ order) {
-    __shared__ unsigned cur[kCostBuckets];
-    if (threadIdx.x < kCostBuckets)
-        cur[threadIdx.x] = table[(int64_t)blockIdx.x * kCostBuckets + threadIdx.x] + table[kCostBlocks * kCostBuckets + threadIdx.x];
-    __syncthreads();
-    const int64_t per = (n + kCostBlocks - 1) / kCostBlocks, lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
+                                                                unsigned *__restrict__ table, int32_t *__restrict__ order) {
+    __shared__ unsigned cur[kCostBuckets], tot[kCostBuckets];
+    cost_cursors(table, cur, tot);
+    const int64_t per = cost_slice_particles(n), lo = per * blockIdx.x, hi = (lo + per < n) ? lo + per : n;
     for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) order[atomicAdd(&cur[bucket[i]], 1u)] = (int32_t)i;
 }
 // ctx->d_bucket (class bytes of n proposals, 127 = needs no solve) -> ctx->d_order; returns where the solve kernel finds the
@@ -181,9 +214,9 @@ __global__ void __launch_bounds__(256) cost_scatter_order_kernel(const uint8_t *
 const unsigned *launch_cost_sort_order(smc_ctx *ctx, int64_t n) {
     if (!ctx->d_order || !ctx->d_bucket || !ctx->d_order_hist) return nullptr;
     hipLaunchKernelGGL(cost_hist_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist);
-    hipLaunchKernelGGL(cost_offsets_kernel, dim3(1), dim3(kCostBuckets), 0, ctx->stream, ctx->d_order_hist);
+    hipLaunchKernelGGL(cost_offsets_kernel, dim3(kCostBuckets), dim3(kCostBlocks), 0, ctx->stream, ctx->d_order_hist, (const MHControl *)nullptr);
     hipLaunchKernelGGL(cost_scatter_order_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist, ctx->d_order);
-    return ctx->d_order_hist + kCostBlocks * kCostBuckets + (kCostBuckets - 1);
+    return cost_n_ordered(ctx);
 }
 
 __global__ void __launch_bounds__(256)
@@ -196,30 +229,10 @@ mm_stiff_scan_kernel(const double *__restrict__ theta, int64_t stride, int64_t n
 // ---------------------------------------------------------------------------------------------
 // proposal (Micmem_SMC_main.py:220-228)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int64_t stride, int64_t n,
-                  double *__restrict__ prop, int64_t pstride, uint8_t *__restrict__ p0_out) {
-    if (blockIdx.x == 0) {   // fused iteration: the counters of this sweep and the work queue of its solve start from zero
-        if (mh.zero_counters && threadIdx.x < sizeof(SweepCounters) / 8)
-            reinterpret_cast<unsigned long long *>(mh.zero_counters)[threadIdx.x] = 0ull;
-        if (mh.zero_queue && threadIdx.x == 64) mh.zero_queue[0] = 0ull;
-        if (mh.stiff.particles && (threadIdx.x == 65 || threadIdx.x == 67)) mh.stiff.count_next[threadIdx.x == 67] = 0u;
-        if (mh.reject_out && threadIdx.x == 66) {   // what mm_certainly_rejected reads during the solve of this sweep
-            RejectArgs r;
-            r.lk1 = mh.reject_lk1;
-            r.rr = mh.rr;
-            r.pratio = mh.pratio;
-            r.gamma = mh.gamma;
-            r.seed = mh.seed;
-            r.stream = mh.stream;
-            r.global_offset = mh.global_offset;
-            r.device_rng = mh.device_rng;
-            r.prior_mode = mh.prior_mode;
-            *mh.reject_out = r;
-        }
-    }
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
+// one proposal (Micmem_SMC_main.py:220-228); s_hist: the block's class histogram in LDS (cost-ordered sweeps)
+__device__ __forceinline__ void mm_propose_one(const Prior &prior, const MHParams &mh, double mh_ratio, const double *__restrict__ filt,
+                                               int64_t stride, int64_t n, double *__restrict__ prop, int64_t pstride,
+                                               uint8_t *__restrict__ p0_out, int64_t p, unsigned *s_hist) {
     const double f0 = filt[p], f1 = filt[stride + p], f2 = filt[2 * stride + p];
     double z0, z1, z2;
     if (mh.device_rng) {
@@ -244,8 +257,8 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
         z2 = mh.noise[2 * n + p];
     }
     // separately rounded multiply and add, as NumPy evaluates `p_filt + noise * mhstep_ratio`
-    const double c0 = __dadd_rn(f0, __dmul_rn(z0, mh.ratio)), c1 = __dadd_rn(f1, __dmul_rn(z1, mh.ratio)),
-                 c2 = __dadd_rn(f2, __dmul_rn(z2, mh.ratio));
+    const double c0 = __dadd_rn(f0, __dmul_rn(z0, mh_ratio)), c1 = __dadd_rn(f1, __dmul_rn(z1, mh_ratio)),
+                 c2 = __dadd_rn(f2, __dmul_rn(z2, mh_ratio));
     // support mask (cal_prior > 0, :225-226) and reset of out-of-support proposals (:228)
     double pdf = prior_pdf(prior.kind[0], prior.a[0], prior.b[0], c0);
     pdf = pdf * prior_pdf(prior.kind[1], prior.a[1], prior.b[1], c1);
@@ -262,7 +275,11 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
     prop[pstride + p] = w1;
     prop[2 * pstride + p] = __dadd_rn(__dmul_rn(c2, p0), __dmul_rn(f2, q0));
     p0_out[p] = (uint8_t)(p0 != 0.0);
-    if (mh.cost_bucket) mh.cost_bucket[p] = (uint8_t)mm_cost_bucket(w0, w1, p0 != 0.0);
+    if (mh.cost_bucket) {
+        const unsigned cls = mm_cost_bucket(w0, w1, p0 != 0.0);
+        mh.cost_bucket[p] = (uint8_t)cls;
+        atomicAdd(&s_hist[cls], 1u);
+    }
     // early rejection reads the siblings' results: none of this sweep's items has finished yet (NaN).  In a cost-ordered sweep
     // the solve kernel never sees an out-of-support proposal: its items are published here (sum 0, no attempts)
     const bool done_here = mh.cost_bucket && p0 == 0.0;
@@ -278,6 +295,47 @@ mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int
     // a proposal inside the support whose solves will be long: onto the list of this sweep (the solve kernel applies the
     // same predicate to the same stored values when it skips the particle in its index-ordered pass)
     if (mh.stiff.particles && p0 != 0.0 && mm_is_stiff(w0, w1)) stiff_list_append(mh.stiff, p, w0, w1);
+}
+__global__ void __launch_bounds__(256)
+mm_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int64_t stride, int64_t n,
+                  double *__restrict__ prop, int64_t pstride, uint8_t *__restrict__ p0_out) {
+    // batch of iterations under device control: nothing of an iteration after the loop's `break` may happen - no counter is
+    // cleared, no list touched, p_pred keeps the proposals of the last iteration that ran (Micmem_SMC_main.py:243-246)
+    if (mh.ctl && mh.ctl->stop) return;
+    const double mh_ratio = mh.ctl ? mh.ctl->ratio : mh.ratio;      // mhstep_ratio (:190,247-249)
+    if (blockIdx.x == 0) {   // fused iteration: the counters of this sweep and the work queue of its solve start from zero
+        if (mh.zero_counters && threadIdx.x < sizeof(SweepCounters) / 8)
+            reinterpret_cast<unsigned long long *>(mh.zero_counters)[threadIdx.x] = 0ull;
+        if (mh.zero_queue && threadIdx.x == 64) mh.zero_queue[0] = 0ull;
+        if (mh.stiff.particles && (threadIdx.x == 65 || threadIdx.x == 67)) mh.stiff.count_next[threadIdx.x == 67] = 0u;
+        if (mh.reject_out && threadIdx.x == 66) {   // what mm_certainly_rejected reads during the solve of this sweep
+            RejectArgs r;
+            r.lk1 = mh.reject_lk1;
+            r.rr = mh.rr;
+            r.pratio = mh.pratio;
+            r.gamma = mh.gamma;
+            r.seed = mh.seed;
+            r.stream = mh.stream;
+            r.global_offset = mh.global_offset;
+            r.device_rng = mh.device_rng;
+            r.prior_mode = mh.prior_mode;
+            *mh.reject_out = r;
+        }
+    }
+    // cost-ordered sweep: the class histogram of this block's 256 proposals, added to the row of the slice the block belongs to
+    // (the counting sort's first pass; its table is zero on entry, see cost_offsets_kernel)
+    __shared__ unsigned s_hist[kCostBuckets];
+    if (mh.cost_bucket) {
+        if (threadIdx.x < kCostBuckets) s_hist[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) mm_propose_one(prior, mh, mh_ratio, filt, stride, n, prop, pstride, p0_out, p, s_hist);
+    if (mh.cost_bucket) {
+        __syncthreads();
+        if (threadIdx.x < kCostBuckets && s_hist[threadIdx.x])
+            atomicAdd(&mh.cost_table[kCostCounts + ((int64_t)blockIdx.x / cost_slice_blocks(n)) * kCostBuckets + threadIdx.x], s_hist[threadIdx.x]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -308,7 +366,9 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     const unsigned *n_ordered;  // ... and how many positions it has: the in-support proposals (the others were published by the
                                 // propose kernel and come last in `order`); nullptr: all n (a probe's uploaded order)
     const SortedProposal *sorted;   // with n_ordered: the proposals in cost order, one 32-byte record per position (written by the
-};                                  // counting sort's scatter): a wave's 64 starts read 2 KB in a row instead of 192 scattered lines
+                                    // counting sort's scatter): a wave's 64 starts read 2 KB in a row instead of 192 scattered lines
+    const MHControl *ctl;           // batch of iterations under device control: the kernel leaves at once when ctl->stop is set
+};
 
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
 // both evaluate the same floating-point expression
@@ -539,6 +599,7 @@ struct MMOps {
 template <bool WRITE_PRED, bool EXACT, bool FAST>
 __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_kernel(MMModel mm, SolveArgs a) {
     extern __shared__ double2 smem_tp[];
+    if (a.ctl && __builtin_amdgcn_readfirstlane(a.ctl->stop)) return;   // the Metropolis loop has ended: nothing to solve (scalar branch)
     const int n_ex = mm.n_ex, n_t = mm.n_t;
     double2 *s_tp = smem_tp;                                        // n_ex rows of n_t + 1 (time, P_obs) pairs, mm_rk45.h
     double *s_S0 = reinterpret_cast<double *>(s_tp + n_ex * (n_t + 1));   // n_ex
@@ -568,6 +629,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                  uint8_t *__restrict__ dbg_r) {
     __shared__ unsigned long long s_cnt[4][4];
     __shared__ double s_mom[4][9];
+    if (MODE == 1 && mh.ctl && mh.ctl->stop) return;   // after the loop's `break`: p_filt, lk1, r_ac and the counters stay as they are
     unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0, long_items = 0;
     // moments of the SELECTED particles about mh.moment_shift (MODE 1, fused iteration): sum y, sum y y^T (upper), y = x - shift
     double m0 = 0, m1 = 0, m2 = 0, c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
@@ -689,9 +751,20 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+// Blocks of the accept kernel: grid-stride, so that counters and moment rows cost one atomic / one row per block.  The cap is
+// what the streaming side needs: 170 B per particle through 7 loads and 5 stores per thread want every CU full of waves
+// (round 3 ran 1024 blocks = 16 waves per CU: 60 us for 10^6 particles, 2.8 TB/s; A/B in profiles/r04_ab_finish_grid.log).
+#ifndef SMC_FINISH_GRID_CAP
+#define SMC_FINISH_GRID_CAP 2048
+#endif
 static unsigned finish_grid(int64_t n) {
+    static const int64_t cap = [] {
+        const char *e = getenv("SMC_FINISH_GRID_CAP");     // A/B knob
+        const int64_t v = e ? atoll(e) : 0;
+        return (v >= 1 && v <= 8192) ? v : (int64_t)SMC_FINISH_GRID_CAP;
+    }();
     const int64_t g = (n + 255) / 256;
-    return (unsigned)(g < 1024 ? (g < 1 ? 1 : g) : 1024);
+    return (unsigned)(g < cap ? (g < 1 ? 1 : g) : cap);
 }
 
 // dynamic LDS of the solve kernel: the (time, observation) table, S0, and the four waves' pools of started items
@@ -737,7 +810,7 @@ static StiffList next_stiff_list(smc_ctx *ctx, int64_t n) {
 
 static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0, double *pred,
                          const StiffList &sl, bool queue_cleared = false, bool reject = false, int patience = 0,
-                         const int32_t *order = nullptr, bool cost_ordered = false) {
+                         const int32_t *order = nullptr, bool cost_ordered = false, const MHControl *ctl = nullptr) {
     const MMModel &mm = ctx->mm;
     SolveArgs a{};
     a.theta = theta;
@@ -756,8 +829,9 @@ static void launch_solve(smc_ctx *ctx, const double *theta, int64_t stride, int6
     a.patience = patience;
     a.order = order;
     // a cost-ordered Metropolis sweep (not a probe's uploaded order): the first position of the last class = the in-support proposals
-    a.n_ordered = cost_ordered ? ctx->d_order_hist + kCostBlocks * kCostBuckets + (kCostBuckets - 1) : nullptr;
+    a.n_ordered = cost_ordered ? cost_n_ordered(ctx) : nullptr;
     a.sorted = static_cast<const SortedProposal *>(ctx->d_sorted);
+    a.ctl = ctl;
 #ifdef SMC_DEBUG_PATIENCE_ENV   // A/B builds only (tools/ab_build.sh): in-phase patience of every sweep from the environment
     if (const char *e = getenv("SMC_DEBUG_PATIENCE")) a.patience = atoi(e);
 #endif
@@ -793,8 +867,10 @@ void launch_mm_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t
     const StiffList sl = next_stiff_list(ctx, n);
     if (sl.particles)
         hipLaunchKernelGGL(mm_stiff_scan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, theta, stride, n, sl);
-    launch_solve(ctx, theta, stride, n, nullptr, pred, sl, false, false, ctx->order_debug ? ctx->order_debug_patience : 0,
-                 ctx->order_debug ? ctx->d_order : nullptr);
+    // a probe's uploaded order (smc_debug_set_order) has n_local entries: a host-batch sweep of another size runs in index order
+    const bool dbg_order = ctx->order_debug && n == ctx->n_local;
+    launch_solve(ctx, theta, stride, n, nullptr, pred, sl, false, false, dbg_order ? ctx->order_debug_patience : 0,
+                 dbg_order ? ctx->d_order : nullptr);
     MHParams mh{};
     hipLaunchKernelGGL((mm_finish_kernel<0>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,
                        theta, stride, n, ctx->d_sum_r2, ctx->d_info, nullptr, lk, nullptr, 0, nullptr, ctx->d_counters,
@@ -822,20 +898,20 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
     const bool cost_order = ctx->cost_order != 0 && ctx->in_phase != 0 && !homogeneous && !ctx->order_debug && n >= 16384 &&
                             ctx->dim == 3 && ctx->d_order && ctx->d_bucket && ctx->d_order_hist && ctx->d_sorted;
     mh.cost_bucket = cost_order ? ctx->d_bucket : nullptr;
+    mh.cost_table = ctx->d_order_hist;
     mh.done_sums = ctx->d_sum_r2;
     mh.done_info = ctx->d_info;
     mh.pending_n_ex = ctx->mm.n_ex;
     hipLaunchKernelGGL(mm_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->prior, mh,
                        F.theta, F.stride, n, P.theta, P.stride, ctx->d_p0);
     if (cost_order) {
-        hipLaunchKernelGGL(cost_hist_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist);
-        hipLaunchKernelGGL(cost_offsets_kernel, dim3(1), dim3(kCostBuckets), 0, ctx->stream, ctx->d_order_hist);
+        hipLaunchKernelGGL(cost_offsets_kernel, dim3(kCostBuckets), dim3(kCostBlocks), 0, ctx->stream, ctx->d_order_hist, mh.ctl);
         hipLaunchKernelGGL(cost_scatter_kernel, dim3(kCostBlocks), dim3(256), 0, ctx->stream, ctx->d_bucket, n, ctx->d_order_hist, P.theta, P.stride,
-                           static_cast<SortedProposal *>(ctx->d_sorted));
+                           static_cast<SortedProposal *>(ctx->d_sorted), mh.ctl);
     }
     const int patience = (ctx->in_phase != 0 && (homogeneous || cost_order)) ? kInPhasePatience : (ctx->order_debug ? ctx->order_debug_patience : 0);
     launch_solve(ctx, P.theta, P.stride, n, ctx->d_p0, nullptr, mh.stiff, mh.zero_queue != nullptr, reject, patience,
-                 ctx->order_debug ? ctx->d_order : nullptr, cost_order);
+                 ctx->order_debug ? ctx->d_order : nullptr, cost_order, mh.ctl);
     ctx->pending_sweep_items = n * ctx->mm.n_ex;
     ctx->moment_rows_n = mh.moment_rows ? (int)finish_grid(n) : 0;
     hipLaunchKernelGGL((mm_finish_kernel<1>), dim3(finish_grid(n)), dim3(256), 0, ctx->stream, ctx->mm, mh,

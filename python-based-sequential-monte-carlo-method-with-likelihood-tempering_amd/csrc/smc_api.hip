@@ -143,7 +143,8 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->d_p0, (size_t)n_local));
     CK(hipMalloc(&c->d_order, (size_t)n_local * sizeof(int32_t)));          // cost order of a Metropolis sweep (mm_kernels.hip)
     CK(hipMalloc(&c->d_bucket, (size_t)n_local));
-    CK(hipMalloc(&c->d_order_hist, (size_t)(256 + 1) * 128 * sizeof(unsigned)));
+    CK(hipMalloc(&c->d_order_hist, cost_table_bytes()));
+    CK(hipMemsetAsync(c->d_order_hist, 0, cost_table_bytes(), c->stream));   // the histogram rows are zero between sweeps
     CK(hipMalloc(&c->d_sorted, (size_t)n_local * 32));
     {
         hipDeviceProp_t prop;
@@ -162,6 +163,15 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->d_fused, 256 * sizeof(double)));
     CK(hipMemsetAsync(c->d_fused, 0, 256 * sizeof(double), c->stream));
     CK(hipHostMalloc(&c->h_fused, 256 * sizeof(double)));
+    CK(hipMalloc(&c->d_ess, 128 * sizeof(double)));          // the fused ESS search's own words (max(lk) + 2 x 32 sums)
+    CK(hipMemsetAsync(c->d_ess, 0, 128 * sizeof(double), c->stream));
+    CK(hipHostMalloc(&c->h_ess, 128 * sizeof(double)));
+    CK(hipMalloc(&c->d_mhctl, sizeof(MHControl)));            // device-side loop control of a batch of Metropolis iterations
+    CK(hipMemsetAsync(c->d_mhctl, 0, sizeof(MHControl), c->stream));
+    CK(hipMalloc(&c->d_mhlog, (kMHBatchMax + 1) * sizeof(MHLogEntry)));
+    CK(hipMemsetAsync(c->d_mhlog, 0, (kMHBatchMax + 1) * sizeof(MHLogEntry), c->stream));
+    CK(hipHostMalloc(&c->h_mhlog, (kMHBatchMax + 1) * sizeof(MHLogEntry)));
+    CK(hipHostMalloc(&c->h_mhctl, sizeof(MHControl)));
     CK(hipHostMalloc(&c->h_small, 4096 * sizeof(double)));
     c->n_tiles = (n_local + kScanTile - 1) / kScanTile;
     CK(hipMalloc(&c->d_oscan, (size_t)n_local * sizeof(int32_t)));
@@ -202,6 +212,12 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_small);
     (void)hipFree(c->d_fused);
     if (c->h_fused) (void)hipHostFree(c->h_fused);
+    (void)hipFree(c->d_ess);
+    if (c->h_ess) (void)hipHostFree(c->h_ess);
+    (void)hipFree(c->d_mhctl);
+    (void)hipFree(c->d_mhlog);
+    if (c->h_mhlog) (void)hipHostFree(c->h_mhlog);
+    if (c->h_mhctl) (void)hipHostFree(c->h_mhctl);
     if (c->h_small) (void)hipHostFree(c->h_small);
     (void)hipFree(c->d_oscan);
     (void)hipFree(c->d_blk_r);
@@ -486,6 +502,7 @@ int smc_download_particles(smc_ctx *c, int set, double *aos, int64_t n) {
 }
 int smc_upload_lk(smc_ctx *c, int set, const double *lk, int64_t n) {
     if (check_set(c, set, n)) return 1;
+    if (set == SMC_SET_PRED) c->ess_max_valid = false;
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemcpyAsync(c->set[set].lk, lk, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -522,6 +539,7 @@ int smc_reset_accept_flags(smc_ctx *c) {
 }
 int smc_commit_filt_to_pred(smc_ctx *c) {
     if (!c) return fail(nullptr, "NULL context");
+    c->ess_max_valid = false;
     HIPC(c, hipSetDevice(c->device));
     const size_t nb = (size_t)c->n_local * sizeof(double);
     HIPC(c, hipMemcpyAsync(c->set[SMC_SET_PRED].theta, c->set[SMC_SET_FILT].theta, nb * c->dim,
@@ -585,6 +603,7 @@ int smc_loglik(smc_ctx *c, int set, int64_t *n_failed, int64_t *rk_attempts) {
     if (check_set(c, set, 0)) return 1;
     if (!c->have_model) return fail(c, "smc_set_model_mm has not been called");
     HIPC(c, hipSetDevice(c->device));
+    if (set == SMC_SET_PRED) c->ess_max_valid = false;
     if (counters_begin(c)) return 1;
     {
         ScopedTimer tm(c, SMC_T_LOGLIK);
@@ -753,14 +772,20 @@ int smc_ess_search_global(smc_ctx *c, const double *gm, int n_cand, int with_max
     if (!c) return fail(nullptr, "NULL context");
     if (n_cand < 1 || n_cand > 2 * SMC_MAX_ESS_CAND) return fail(c, "smc_ess_search_global: n_cand must be 1 .. 32");
     HIPC(c, hipSetDevice(c->device));
-    constexpr int kMaxAt = 200, kSumsAt = 208;       // d_small layout of this call: [kMaxAt] max(lk), [kSumsAt ..) 2 x 32 sums
-    double *S = c->d_small;
+    // The search's own buffer: with_max == 0 relies on max(lk) still being where the previous call left it, and
+    // every other entry point with a small result writes d_small - a host all-reduce between two calls of one search must
+    // not be able to change the maximum the second pass normalises with.  Nothing else writes d_ess.
+    constexpr int kMaxAt = 0, kSumsAt = 8;           // d_ess layout: [kMaxAt] max(lk), [kSumsAt ..) 2 x 32 sums (padded)
+    double *S = c->d_ess;
     if (with_max) {
         {
             ScopedTimer tm(c, SMC_T_MAX);
             launch_max(c, c->set[SMC_SET_PRED].lk, c->n_local, S + kMaxAt);
         }
         if (dev_allreduce(c, S + kMaxAt, 1, ncclDouble, ncclMax)) return 1;
+        c->ess_max_valid = true;
+    } else if (!c->ess_max_valid) {
+        return fail(c, "smc_ess_search_global: with_max == 0 needs an earlier call with with_max != 0 on the same lk");
     }
     const int n_a = n_cand < SMC_MAX_ESS_CAND ? n_cand : SMC_MAX_ESS_CAND, n_b = n_cand - n_a;
     const int pad_a = ess_padded_k(n_a), pad_b = n_b > 0 ? ess_padded_k(n_b) : 0;
@@ -772,14 +797,14 @@ int smc_ess_search_global(smc_ctx *c, const double *gm, int n_cand, int with_max
     HIPC(c, hipGetLastError());
     const int nv = 2 * (pad_a + pad_b);
     if (dev_allreduce(c, S + kSumsAt, (size_t)nv, ncclDouble, ncclSum)) return 1;
-    HIPC(c, hipMemcpyAsync(c->h_small + kMaxAt, S + kMaxAt, (size_t)(kSumsAt - kMaxAt + nv) * sizeof(double), hipMemcpyDeviceToHost,
+    HIPC(c, hipMemcpyAsync(c->h_ess + kMaxAt, S + kMaxAt, (size_t)(kSumsAt - kMaxAt + nv) * sizeof(double), hipMemcpyDeviceToHost,
                            c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
-    if (max_lk) *max_lk = c->h_small[kMaxAt];
+    if (max_lk) *max_lk = c->h_ess[kMaxAt];
     for (int k = 0; k < n_cand; ++k) {
         const int at = kSumsAt + (k < n_a ? 2 * k : 2 * pad_a + 2 * (k - n_a));
-        sum_w[k] = c->h_small[at];
-        sum_w2[k] = c->h_small[at + 1];
+        sum_w[k] = c->h_ess[at];
+        sum_w2[k] = c->h_ess[at + 1];
     }
     return 0;
 }
@@ -1245,6 +1270,124 @@ int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, c
     if (rk_attempts_local) *rk_attempts_local = (int64_t)c->h_counters->rk_attempts;
     if (cov_m)
         for (int i = 0; i < d * d; ++i) cov_m[i] = c->h_fused[kCov + i];
+    return 0;
+}
+
+// A BATCH of Metropolis iterations with the loop control of Micmem_SMC_main.py:243-249 on the device: the
+// host enqueues n_iter iterations back to back and synchronises ONCE.  Between two iterations mh_control_kernel (one block,
+// stage_kernels.hip) does what the driver's Python did on the counts it had just read back: break when r_ac.sum() > r_th * N,
+// halve mhstep_ratio when r_ac.sum() < r_threshold_min * N, and form the next iteration's cov_m and factor; every kernel of an
+// iteration after the break returns at once (ctl->stop).  With RCCL the counts this kernel reads were all-reduced on the
+// stream just before it, so every rank takes the same decision and the enqueued collectives stay matched.  Stream order per
+// iteration (one rank):  control -> propose -> [cost_hist, cost_offsets, cost_scatter] -> solve -> accept  - the row reduction
+// of the moments and the factor live in the control kernel; several ranks:  ... -> accept -> moments_reduce -> ncclAllReduce
+// -> control.  What the host decides once per batch instead of once per sweep: in phase / cost order (from the last sweep
+// before the batch); neither can change a result.
+int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed, uint64_t stream0,
+                             int n_iter, double thr_stop, double thr_halve, int64_t global_offset, int *n_done, int *stopped,
+                             double *ratio_next, int64_t *accepted_now, int64_t *accepted_ever, int64_t *n_failed,
+                             int64_t *rk_attempts_local, double *ratio_used, double *cov_m) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
+    if (c->model_kind != 1) return fail(c, "smc_mh_sweeps_device_rng: Michaelis-Menten model only (the other models take smc_mh_iteration_device_rng)");
+    if (!w_cov) return fail(c, "smc_mh_sweeps_device_rng: w_cov is NULL");
+    if (n_iter < 1 || n_iter > kMHBatchMax) return fail(c, "smc_mh_sweeps_device_rng: n_iter must be 1 .. 32");
+    if (c->world > 1 && !c->nccl_comm) return fail(c, "world > 1 but smc_comm_init has not been called (the batch needs RCCL)");
+    HIPC(c, hipSetDevice(c->device));
+    const int d = c->dim, nv = d + d * (d + 1) / 2;
+    const bool one_rank = c->nccl_comm == nullptr;
+    double *S = c->d_fused;
+    MHControlArgs a{};
+    a.ctl = c->d_mhctl;
+    a.log = c->d_mhlog;
+    a.ratio0 = mhstep_ratio;
+    a.thr_stop = thr_stop;
+    a.thr_halve = thr_halve;
+    a.nv = nv;
+    a.vec = S + kV;
+    a.counters = c->d_counters;
+    a.n_global = (double)c->n_global;
+    a.shift_io = S + kShift;
+    a.cov_out = S + kCov;
+    a.xform_out = S + kXf;
+    const int parity0 = c->stiff_parity;
+    ScopedTimer tm_mh(c, SMC_T_MH);
+    {   // the first iteration's factor: carried moments, or np.cov's two-pass route when the FILT set changed since
+        ScopedTimer tm(c, SMC_T_MOMENTS);
+        a.mode = kCtlInit | kCtlTransform;
+        a.iteration = 0;
+        if (c->moments_valid) {
+            a.mom = S + kV;
+            a.sums = nullptr;
+        } else {
+            launch_moment_sums(c, S + kSums);
+            if (dev_allreduce(c, S + kSums, (size_t)d, ncclDouble, ncclSum)) return 1;
+            launch_moment_centered_dev(c, S + kSums, S + kCent);
+            if (dev_allreduce(c, S + kCent, (size_t)(d * (d + 1) / 2), ncclDouble, ncclSum)) return 1;
+            a.mom = S + kCent;
+            a.sums = S + kSums;
+        }
+        launch_mh_control(c, a, w_cov);
+    }
+    c->moments_valid = false;
+    for (int i = 0; i < n_iter; ++i) {
+        MHParams mh{};
+        mh.gamma = gamma;
+        mh.ratio = mhstep_ratio;       // not read: the kernels take ctl->ratio
+        mh.device_rng = 1;
+        mh.prior_mode = c->prior_mode;
+        mh.pratio = c->d_pratio;
+        mh.seed = seed;
+        mh.stream = stream0 + (uint64_t)i;
+        mh.global_offset = global_offset;
+        mh.transform_dev = S + kXf;
+        mh.zero_counters = c->d_counters;
+        mh.zero_queue = c->d_queue;
+        mh.moment_shift = S + kShift;
+        mh.moment_rows = c->d_partials;
+        mh.ctl = c->d_mhctl;
+        launch_mm_mh(c, c->n_local, mh);
+        HIPC(c, hipGetLastError());
+        if (c->launch_failed) { c->launch_failed = false; return 1; }
+        if (!one_rank) {
+            launch_moments_reduce(c, c->moment_rows_n, nv, S + kV, c->d_mhctl);
+            if (dev_allreduce(c, S + kV, (size_t)nv + 3, ncclDouble, ncclSum)) return 1;
+        }
+        ScopedTimer tm(c, SMC_T_MOMENTS);
+        a.mode = kCtlDecide | (i + 1 < n_iter ? kCtlTransform : 0);
+        a.iteration = i + 1;
+        a.rows = one_rank ? c->d_partials : nullptr;
+        a.n_rows = c->moment_rows_n;
+        a.mom = S + kV;
+        a.sums = nullptr;
+        launch_mh_control(c, a, w_cov);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->h_mhlog, c->d_mhlog, (size_t)(n_iter + 1) * sizeof(MHLogEntry), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_mhctl, c->d_mhctl, sizeof(MHControl), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_fused, S, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));          // the one synchronisation of the batch
+    const int done = c->h_mhctl->n_done;
+    if (done < 1 || done > n_iter) return fail(c, "smc_mh_sweeps_device_rng: the device reports an impossible iteration count");
+    c->moments_valid = true;           // S + kV: moments of the particles the last iteration that ran selected
+    c->stiff_parity = parity0 ^ (done & 1);     // the lists of the iterations after the break were never built: their counters
+                                                // are as the last iteration that ran left them (cleared for its successor)
+    c->pending_sweep_items = 0;
+    c->last_sweep_items = c->n_local * c->mm.n_ex;
+    c->last_sweep_long_items = (int64_t)c->h_mhlog[done - 1].long_items;
+    if (n_done) *n_done = done;
+    if (stopped) *stopped = c->h_mhctl->stop;
+    if (ratio_next) *ratio_next = c->h_mhctl->ratio;
+    for (int i = 0; i < done; ++i) {
+        const MHLogEntry &e = c->h_mhlog[i];
+        if (accepted_now) accepted_now[i] = (int64_t)e.accepted_now;
+        if (accepted_ever) accepted_ever[i] = (int64_t)e.accepted_ever;
+        if (n_failed) n_failed[i] = (int64_t)e.n_failed;
+        if (rk_attempts_local) rk_attempts_local[i] = (int64_t)e.rk_attempts;
+        if (ratio_used) ratio_used[i] = e.ratio;
+        if (cov_m)
+            for (int q = 0; q < d * d; ++q) cov_m[(size_t)i * d * d + q] = e.cov[q];
+    }
     return 0;
 }
 

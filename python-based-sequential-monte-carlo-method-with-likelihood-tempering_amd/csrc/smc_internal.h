@@ -65,6 +65,41 @@ struct StiffList {
     unsigned solo_cap;          // solo entries this sweep's grid can run at once (one per wave): the rest join the ordinary list
 };
 
+// Loop control of a batch of Metropolis iterations on the device (stage_kernels.hip: mh_control_kernel;
+// Micmem_SMC_main.py:243-249).  One block in device memory per context; every kernel of an iteration that belongs to a batch
+// reads `stop` first thing and returns at once when it is set.
+struct MHControl {
+    int stop;                   // the loop has ended (break at :243-246, or a failed solve)
+    int n_done;                 // iterations of the batch that ran
+    double ratio;               // mhstep_ratio of the next iteration (:190, halved at :247-249)
+    double thr_stop, thr_halve; // r_th * n_particle, r_threshold_min * n_particle
+};
+struct MHLogEntry {             // what the driver's Python kept per iteration (mh_log) and counted (account)
+    double ratio;               // mhstep_ratio the iteration drew its proposals with
+    double accepted_now, accepted_ever, n_failed;   // totals over all ranks
+    unsigned long long rk_attempts, long_items;     // this rank's
+    double cov[SMC_MAX_DIM * SMC_MAX_DIM];          // cov_m of the iteration (:212-215)
+};
+constexpr int kMHBatchMax = 32;                     // iterations per batch (ad_mhstep_num is 20)
+constexpr int kCtlInit = 1, kCtlDecide = 2, kCtlTransform = 4;
+struct SweepCounters;
+struct MHControlArgs {
+    MHControl *ctl;
+    MHLogEntry *log;
+    int mode;                   // kCtl* flags
+    int iteration;              // DECIDE: iteration - 1 has just ended; TRANSFORM: iteration is about to start (within the batch)
+    double ratio0, thr_stop, thr_halve;   // INIT
+    // DECIDE
+    const double *rows;         // one rank: per-block moment rows of the accept kernel (nullptr: vec is already reduced)
+    int n_rows, nv;
+    double *vec;                // [moments (nv) | accepted_now, accepted_ever, n_failed]
+    const SweepCounters *counters;
+    // TRANSFORM (mh_transform_body)
+    const double *mom, *sums;
+    double n_global;
+    double *shift_io, *cov_out, *xform_out;
+};
+
 struct MHParams {    // passed by value to the fused MH kernel
     double gamma, ratio;
     const double *noise;  // host-RNG mode: SoA d x n (device); nullptr in device-RNG mode
@@ -90,7 +125,9 @@ struct MHParams {    // passed by value to the fused MH kernel
     RejectArgs *reject_out;     // nullptr: early rejection off in this sweep
     const double *reject_lk1;
     StiffList stiff;            // particles == nullptr: no list
+    const MHControl *ctl;       // batch of iterations under device control: stop flag and mhstep_ratio live here (nullptr: mh.ratio)
     uint8_t *cost_bucket;       // cost order of the sweep (mm_kernels.hip: mm_cost_bucket): one byte per proposal, or nullptr
+    unsigned *cost_table;       // ... and the counting sort's table, whose histogram rows the propose kernel's blocks add to
     double *done_sums;          // ... whose out-of-support proposals the propose kernel publishes itself ([e * n + p])
     int *done_info;
 };
@@ -149,6 +186,11 @@ struct smc_ctx {
     int64_t partials_cap = 0;
     double *d_small = nullptr, *h_small = nullptr;  // small results (device / pinned host), 4096 doubles
     double *d_fused = nullptr, *h_fused = nullptr;  // the fused Metropolis iteration's own 256 doubles (carried moments, cov_m, factor)
+    double *d_ess = nullptr, *h_ess = nullptr;      // the fused ESS search's own 128 doubles: max(lk) and the candidates' sums
+    bool ess_max_valid = false;                     // d_ess[0] holds max over the PRED set's lk as it is now
+    smc::MHControl *d_mhctl = nullptr;              // device-side loop control of a batch of Metropolis iterations
+    smc::MHLogEntry *d_mhlog = nullptr, *h_mhlog = nullptr;   // its per-iteration log (kMHBatchMax + 1 entries; host copy pinned)
+    smc::MHControl *h_mhctl = nullptr;              // pinned copy of the control block, read back with the log
     // resampling
     int32_t *d_oscan = nullptr;      // inclusive offspring scan (n_local)
     double *d_blk_r = nullptr;       // per tile: residual sums, then exclusive prefix
@@ -223,6 +265,8 @@ void launch_mm_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);   // mh.moment_r
 int query_solve_blocks_per_cu(bool fast);
 // in-phase patience of homogeneous and of cost-ordered sweeps (solve_sched.h; profiles/r03_ab_patience.log, r03_ab_cost_order.log)
 constexpr int kInPhasePatience = 12;
+size_t cost_table_bytes();                  // mm_kernels.hip: size of ctx->d_order_hist
+const unsigned *cost_n_ordered(const smc_ctx *ctx);   // ... and where the solve kernels find the number of ordered positions
 const unsigned *launch_cost_sort_order(smc_ctx *ctx, int64_t n);   // mm_kernels.hip: counting sort of ctx->d_bucket into ctx->d_order
 // implemented in meth_smc.hip
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);

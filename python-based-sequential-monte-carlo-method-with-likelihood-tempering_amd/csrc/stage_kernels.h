@@ -16,7 +16,8 @@ void launch_moment_centered(smc_ctx *c, const double *mean, double *d_out);
 void launch_moment_centered_dev(smc_ctx *c, const double *d_sums, double *d_out);   // mean = d_sums / n_global on the device
 void launch_mh_transform(smc_ctx *c, const double *d_mom, const double *d_sums, const double *w_cov, double *d_shift,
                          double *d_cov, double *d_xform);
-void launch_moments_reduce(smc_ctx *c, int n_rows, int nv, double *d_out);
+void launch_moments_reduce(smc_ctx *c, int n_rows, int nv, double *d_out, const MHControl *ctl = nullptr);
+void launch_mh_control(smc_ctx *c, const MHControlArgs &a, const double *w_cov);   // one block: decide / transform (stage_kernels.hip)
 void launch_resample_phase1(smc_ctx *c, double max_lk, double gm, double sum_w);
 void launch_resample_phase2(smc_ctx *c, double max_lk, double gm, double sum_w, double base, double wrand);
 void launch_offspring_from_scan(smc_ctx *c, int64_t *d_out);

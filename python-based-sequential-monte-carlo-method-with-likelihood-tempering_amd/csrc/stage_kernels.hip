@@ -294,12 +294,11 @@ struct WCov {
 //                    previous iteration about the mean of the iteration before (so |E y| << spread: no cancellation to speak
 //                    of): cov = E[y y^T] - E[y] E[y]^T, and the shift moves on to the new mean.
 template <int D>
-__global__ void mh_transform_kernel(const double *__restrict__ mom, const double *__restrict__ sums, double n_global, WCov wcov,
-                                    double *__restrict__ shift_io, double *__restrict__ cov_out,
-                                    double *__restrict__ xform_out) {
+__device__ __forceinline__ void mh_transform_body(const double *__restrict__ mom, const double *__restrict__ sums, double n_global,
+                                                  const WCov &wcov, double *__restrict__ shift_io, double *__restrict__ cov_out,
+                                                  double *__restrict__ xform_out) {
     // D is a compile-time constant and every loop below is unrolled, so A and V live in registers: the first version, with
     // run-time d and SMC_MAX_DIM arrays in scratch, took 23 us per call - on the critical path of every iteration
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     constexpr int d = D;
     double A[D][D], V[D][D];
     const double inv_n = 1.0 / n_global;     // np.true_divide(1, fact), then c *= that (np.cov)
@@ -397,6 +396,84 @@ __global__ void mh_transform_kernel(const double *__restrict__ mom, const double
         const double sg = (big < 0.0) ? -1.0 : 1.0;
 #pragma unroll
         for (int c = 0; c < d; ++c) xform_out[rank * d + c] = sv * (sg * V[c][e]);
+    }
+}
+template <int D>
+__global__ void mh_transform_kernel(const double *__restrict__ mom, const double *__restrict__ sums, double n_global, WCov wcov,
+                                    double *__restrict__ shift_io, double *__restrict__ cov_out,
+                                    double *__restrict__ xform_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    mh_transform_body<D>(mom, sums, n_global, wcov, shift_io, cov_out, xform_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loop control of the Metropolis iterations ON THE DEVICE (Micmem_SMC_main.py:243-249)
+// ---------------------------------------------------------------------------------------------
+// The host enqueues a batch of iterations back to back; between two of them this kernel (one block) does what the driver's
+// Python did after a synchronisation:
+//   DECIDE     the iteration that has just ended: [W == 1: per-block moment rows of its accept kernel -> S+kV, in
+//              moments_reduce_kernel's summation order]; its totals go into the batch log; `break` if r_ac.sum() > r_th * N
+//              (:243-246) - ctl->stop, which every kernel of the later iterations of the batch tests first thing - else
+//              mhstep_ratio *= 0.5 if r_ac.sum() < r_threshold_min * N (:247-249); a failed solve also ends the loop (the
+//              driver raises, as the reference does);
+//   TRANSFORM  the iteration about to start: cov_m * w_cov and its multivariate_normal factor (mh_transform_body), logged.
+// The thresholds are doubles computed by the host exactly as Python evaluates `r_th * n_particle`; the counts are exact in a
+// double, so `count > thr` is Python's int-vs-float comparison.  With several ranks the counts in S+kV are already summed by
+// the all-reduce that precedes this kernel on the stream: every rank takes the same decision.
+template <int D>
+__global__ void __launch_bounds__(kScanBlock) mh_control_kernel(MHControlArgs a, WCov wcov) {
+    __shared__ double lds[4];
+    MHControl *ctl = a.ctl;
+    const int t = threadIdx.x;
+    if (a.mode & kCtlInit) {
+        if (t == 0) {
+            ctl->stop = 0;
+            ctl->n_done = 0;
+            ctl->ratio = a.ratio0;
+            ctl->thr_stop = a.thr_stop;
+            ctl->thr_halve = a.thr_halve;
+        }
+    } else if (ctl->stop) {
+        return;
+    }
+    constexpr int nv = D + D * (D + 1) / 2;
+    if (a.mode & kCtlDecide) {
+        if (a.rows) {      // one rank: no all-reduce between the accept kernel and this one, so the row reduction happens here
+            for (int v = 0; v < a.nv; ++v) {
+                double s = 0.0;
+                for (int i = t; i < a.n_rows; i += blockDim.x) s += a.rows[(size_t)i * a.nv + v];
+                s = block_sum(s, lds);
+                if (t == 0) a.vec[v] = s;
+            }
+            if (t == 0) {
+                a.vec[a.nv] = (double)a.counters->accepted_now;
+                a.vec[a.nv + 1] = (double)a.counters->accepted_ever;
+                a.vec[a.nv + 2] = (double)a.counters->n_failed;
+            }
+        }
+    }
+    if (t != 0) return;
+    if (a.mode & kCtlDecide) {
+        const double acc_now = a.vec[a.nv], acc_ever = a.vec[a.nv + 1], n_failed = a.vec[a.nv + 2];
+        MHLogEntry &e = a.log[a.iteration - 1];
+        e.accepted_now = acc_now;
+        e.accepted_ever = acc_ever;
+        e.n_failed = n_failed;
+        e.rk_attempts = a.counters->rk_attempts;       // this rank's
+        e.long_items = a.counters->long_items;
+        ctl->n_done = a.iteration;
+        if (acc_ever > ctl->thr_stop || n_failed != 0.0) {
+            ctl->stop = 1;
+            return;
+        }
+        if (acc_ever < ctl->thr_halve) ctl->ratio = ctl->ratio * 0.5;
+    }
+    if (a.mode & kCtlTransform) {
+        static_assert(nv <= SMC_MAX_DIM + SMC_MAX_DIM * (SMC_MAX_DIM + 1) / 2, "");
+        mh_transform_body<D>(a.mom, a.sums, a.n_global, wcov, a.shift_io, a.cov_out, a.xform_out);
+        MHLogEntry &e = a.log[a.iteration];
+        e.ratio = ctl->ratio;
+        for (int i = 0; i < D * D; ++i) e.cov[i] = a.cov_out[i];
     }
 }
 
@@ -764,13 +841,33 @@ void launch_mh_transform(smc_ctx *c, const double *d_mom, const double *d_sums, 
 #undef SMC_XF
     static_assert(SMC_MAX_DIM == 8, "one instantiation of mh_transform_kernel per dimension");
 }
+void launch_mh_control(smc_ctx *c, const MHControlArgs &a, const double *w_cov) {
+    WCov w{};
+    for (int i = 0; i < c->dim * c->dim; ++i) w.w[i] = w_cov[i];
+#define SMC_CT(D) case D: hipLaunchKernelGGL((mh_control_kernel<D>), dim3(1), dim3(kScanBlock), 0, c->stream, a, w); break
+    switch (c->dim) {
+        SMC_CT(1); SMC_CT(2); SMC_CT(3); SMC_CT(4); SMC_CT(5); SMC_CT(6); SMC_CT(7); SMC_CT(8);
+    }
+#undef SMC_CT
+}
 // per-block rows of nv doubles (accept kernel) -> out[0..nv), then the sweep's accept counters as doubles (exact below 2^53):
 // out[nv] = accepted_now, out[nv+1] = accepted_ever, out[nv+2] = n_failed - ONE vector for ONE all-reduce per iteration
+// ctl (batch of iterations under device control): after the loop has ended nothing new was accumulated - but the all-reduce
+// that follows on the stream still runs on every rank, so rank 0 keeps the vector of the last iteration that ran and the
+// other ranks contribute zeros: the sum leaves it (and with it the carried moments) unchanged.
 __global__ void __launch_bounds__(kScanBlock) moments_reduce_kernel(const double *__restrict__ rows, int n_rows, int nv,
                                                                     const SweepCounters *__restrict__ counters,
-                                                                    double *__restrict__ out) {
+                                                                    double *__restrict__ out, const MHControl *__restrict__ ctl,
+                                                                    int rank) {
     __shared__ double lds[4];
     const int v = blockIdx.x;          // one block per value, the last block carries the counters
+    if (ctl && ctl->stop) {
+        if (rank != 0 && threadIdx.x == 0) {
+            if (v < nv) out[v] = 0.0;
+            else out[nv] = out[nv + 1] = out[nv + 2] = 0.0;
+        }
+        return;
+    }
     if (v < nv) {
         double s = 0.0;
         for (int i = threadIdx.x; i < n_rows; i += blockDim.x) s += rows[(size_t)i * nv + v];
@@ -782,9 +879,9 @@ __global__ void __launch_bounds__(kScanBlock) moments_reduce_kernel(const double
         out[nv + 2] = (double)counters->n_failed;
     }
 }
-void launch_moments_reduce(smc_ctx *c, int n_rows, int nv, double *d_out) {
+void launch_moments_reduce(smc_ctx *c, int n_rows, int nv, double *d_out, const MHControl *ctl) {
     hipLaunchKernelGGL(moments_reduce_kernel, dim3(nv + 1), dim3(kScanBlock), 0, c->stream, c->d_partials, n_rows, nv, c->d_counters,
-                       d_out);
+                       d_out, ctl, c->rank);
 }
 
 static ResampleArgs make_args(smc_ctx *c, double max_lk, double gm, double sum_w, double wrand, double base) {

@@ -63,6 +63,9 @@ class SMCSettings:
     stiff_first: bool = True          # hand the predictably long solves out first (same results; HipEngine.set_stiff_first)
     in_phase: bool = True             # homogeneous Metropolis sweeps run their waves in phase (same results; HipEngine.set_in_phase)
     cost_order: bool = True           # heterogeneous ones hand their solves out by cost class, in phase (same results; set_cost_order)
+    mh_batch: object = "auto"         # Metropolis iterations enqueued per host synchronisation, their loop control (main:243-249) on the
+                                      # device (HipEngine.mh_sweeps_device_rng; device RNG, Michaelis-Menten): "auto" = as many as the
+                                      # previous tempering step needed, an int = that many, 0 = one call and one decision per iteration
     priors: dict = field(default_factory=lambda: {
         "Vmax": {"dist": "uniform", "low": 0, "high": 10},
         "Km": {"dist": "uniform", "low": 0, "high": 10},
@@ -335,7 +338,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         engine.set_exact_pow(rng == "numpy")
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
-             "ess_launches": 0, "ess_syncs": 0, "ess_search_s": 0.0, "particle_mutation_steps": 0}
+             "ess_launches": 0, "ess_syncs": 0, "ess_search_s": 0.0, "particle_mutation_steps": 0,
+             "mh_syncs": 0, "mh_noop_sweeps": 0}       # host synchronisations of the Metropolis loops; enqueued sweeps that found the loop ended
 
     meth = getattr(engine, "model", ("",))[0] == "methanation"
 
@@ -424,7 +428,45 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         acc_ever = 0
         mh_log = []
         fused = rng == "device" and _on_device(comm)
-        for j in range(nMH):                                                  # :209
+        batched = (fused and s.mh_batch not in (0, None) and getattr(engine, "mh_sweeps_device_rng", None) is not None
+                   and getattr(engine, "model", ("",))[0] == "mm")
+        if batched:
+            # The same loop with its control on the device: the iterations are enqueued back to back, the engine's control
+            # kernel takes the decisions of :243-249 between them, and the host synchronises once per batch (as a rule once per
+            # tempering step).  What Python did per iteration - counting, logging, raising on a failed solve - happens here
+            # on the batch's log, in the same order.  Every rank computes the same batch sizes (they depend on records only).
+            done, stopped = 0, False
+            depth = s.mh_batch
+            if depth == "auto":      # as many as the previous step's loop took; a first batch that turns out short is continued
+                depth = (records[-1]["last_j"] + 1) if records else 2
+            while done < nMH and not stopped:
+                k = max(1, min(int(depth), nMH - done, 32))
+                out = engine.mh_sweeps_device_rng(gamma_new, mhstep_ratio, w_cov, seed_device, (step << 16) | done, k,
+                                                  r_th * n, s.r_threshold_min * n, lo)
+                stats["mh_syncs"] += 1
+                stats["mh_noop_sweeps"] += k - out["n_done"]
+                for it in out["iterations"]:
+                    account({"rk_attempts": it["rk_attempts"], "n_failed": 0})
+                    stats["rk_attempts_mh"] += it["rk_attempts"]
+                    stats["mutation_sweeps"] += 1
+                    stats["particle_mutation_steps"] += n
+                    acc_ever = it["accepted_ever"]
+                    mh_log.append({"cov_m": it["cov_m"], "mhstep_ratio": it["mhstep_ratio"], "accepted_now": it["accepted_now"],
+                                   "accepted_ever": acc_ever})
+                    if it["n_failed"]:
+                        raise RuntimeError("an RK45 solve failed during an MH sweep (the reference raises here)")
+                    if verbose and rank == 0:
+                        if acc_ever > r_th * n:                               # :243
+                            log(f"r_ac.sum() > r_th * n_particle:{float(acc_ever)}")
+                        elif acc_ever < s.r_threshold_min * n:                # :247
+                            log(it["mhstep_ratio"] * 0.5)
+                done += out["n_done"]
+                stopped = out["stopped"]
+                mhstep_ratio = out["ratio_next"]
+                depth = 1 if s.mh_batch == "auto" else depth
+            j = done - 1
+        for j in ([] if batched else range(nMH)):                             # :209
+            stats["mh_syncs"] += 1
             if fused:                                                         # :212-241 in one call, one synchronisation
                 out = engine.mh_iteration_device_rng(gamma_new, mhstep_ratio, w_cov, seed_device, (step << 16) | j, lo)
                 cov_m = out["cov_m"]

@@ -338,6 +338,25 @@ class HipEngine:
         return {"accepted_now": o[0].value, "accepted_ever": o[1].value, "n_failed": o[2].value,
                 "rk_attempts": o[3].value, "cov_m": cov}
 
+    def mh_sweeps_device_rng(self, gamma, mhstep_ratio, w_cov, seed, stream0, n_iter, thr_stop, thr_halve, global_offset=0):
+        """A batch of n_iter fused Metropolis iterations with the loop control (break / halve mhstep_ratio, Micmem_SMC_main.py:
+        243-249) on the device and ONE synchronisation (include/smc_hip.h: smc_mh_sweeps_device_rng).  Returns how many ran,
+        whether the loop ended by its break, the mhstep_ratio a following batch starts with, and one record per iteration that
+        ran (counts are totals over all ranks, rk_attempts this rank's)."""
+        w_cov = _f64(w_cov, (self.dim, self.dim))
+        k = int(n_iter)
+        nd, st, rn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_double(0)
+        an, ae, nf, at = (np.zeros(k, dtype=np.int64) for _ in range(4))
+        ru, cov = np.zeros(k), np.zeros((k, self.dim, self.dim))
+        self._ck(self.L.smc_mh_sweeps_device_rng(self.ctx, float(gamma), float(mhstep_ratio), _dp(w_cov), int(seed), int(stream0), k,
+                                                 float(thr_stop), float(thr_halve), int(global_offset), ctypes.byref(nd),
+                                                 ctypes.byref(st), ctypes.byref(rn), an.ctypes.data_as(B.c_i64p),
+                                                 ae.ctypes.data_as(B.c_i64p), nf.ctypes.data_as(B.c_i64p),
+                                                 at.ctypes.data_as(B.c_i64p), _dp(ru), _dp(cov)), "smc_mh_sweeps_device_rng")
+        its = [{"accepted_now": int(an[i]), "accepted_ever": int(ae[i]), "n_failed": int(nf[i]), "rk_attempts": int(at[i]),
+                "mhstep_ratio": float(ru[i]), "cov_m": cov[i].copy()} for i in range(nd.value)]
+        return {"n_done": nd.value, "stopped": bool(st.value), "ratio_next": rn.value, "iterations": its}
+
     def proposal_factor_device(self, w_cov):
         """cov_m = np.cov(p_filt.T, bias=True) * w_cov over all ranks and its multivariate_normal factor, both on the device."""
         w_cov = _f64(w_cov, (self.dim, self.dim))

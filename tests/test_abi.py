@@ -18,7 +18,9 @@ def test_library_exports_every_declared_symbol(pkg):
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(declared) == set(pkg.binding.SIGNATURES), set(declared) ^ set(pkg.binding.SIGNATURES)
-    assert L.smc_abi_version() == 1
+    assert L.smc_abi_version() == pkg.binding.SMC_ABI_VERSION == 2      # 2: smc_meth_sweep_check writes five words
+    hdr = open(pkg.binding.HEADER_PATH).read()
+    assert "#define SMC_ABI_VERSION 2" in hdr
 
 
 def test_exported_symbols_are_plain_c(pkg):

@@ -1281,6 +1281,40 @@ def test_cost_ordered_handout_changes_no_result(pkg, data, n):
     assert np.isfinite(res[True][3]).all()
 
 
+def test_cost_ordered_handout_solves_in_support_proposals_without_a_cost_ratio(pkg, data):
+    """under a normal prior on Km every proposal is in the support, also those with Km <= 0 - which have no
+    Vmax / Km cost ratio.  They used to share the counting sort's last class with the out-of-support proposals, which the
+    solve kernel never visits: nobody wrote their sums (early rejection on: NaN -> a poisoned lk1; off: the previous sweep's
+    stale sums fed the accept test).  With the fix they sit in a real class and are solved like any other: four fused
+    iterations with the cost order on and off give the same accept counts, the same FAILURE counts (most of these solves run
+    into the pole S = -Km and fail, as SciPy's would), particles and likelihoods."""
+    n = 32768
+    priors = {"Vmax": {"dist": "uniform", "low": 0, "high": 10}, "Km": {"dist": "normal", "mu": 0.05, "sigma": 0.2},
+              "sigma": {"dist": "uniform", "low": 0, "high": 10}}
+    s = pkg.SMCSettings(n_particle=n, priors=priors)
+    w_cov = s.w_cov()
+    rs = np.random.RandomState(21)
+    th = np.column_stack([rs.uniform(0.5, 3.0, n), rs.uniform(0.01, 0.12, n), rs.uniform(0.01, 0.5, n)])
+    res = {}
+    for on in (True, False):
+        with make_engine(pkg, data, n, priors=priors) as eng:
+            eng.set_cost_order(on)
+            eng.upload_particles(pkg.SMC_SET_PRED, th)
+            assert eng.loglik(pkg.SMC_SET_PRED)["n_failed"] == 0
+            eng.upload_particles(pkg.SMC_SET_FILT, th)
+            eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+            outs, props = [], []
+            for j in range(4):
+                outs.append(eng.mh_iteration_device_rng(0.01, 1.0, w_cov, 13, (5 << 16) | j, 0))
+                props.append(eng.download_particles(pkg.SMC_SET_PRED))
+            res[on] = ([o["accepted_now"] for o in outs], [o["n_failed"] for o in outs], eng.download_particles(pkg.SMC_SET_FILT),
+                       eng.download_lk(pkg.SMC_SET_FILT), props)
+    assert (res[True][4][0][:, 1] <= 0).sum() > n // 50          # the case is really there: proposals with Km <= 0 ...
+    assert res[True][0] == res[False][0] and res[True][1] == res[False][1]
+    assert np.array_equal(res[True][2], res[False][2]) and np.array_equal(res[True][3], res[False][3], equal_nan=True)
+    assert np.isfinite(res[True][3]).all()                        # ... and none of them ever poisoned a stored likelihood
+
+
 def test_item_records_of_a_sweep_add_up_to_its_counters(pkg, data):
     """smc_download_item_info (diagnostics, tools/sweep_tail_census.py): the per-(experiment, particle) records of a likelihood
     sweep - attempts | cancelled << 29 | failed << 30 - sum to the sweep's device-counted attempts; after a Metropolis sweep in
@@ -1370,3 +1404,89 @@ def test_in_phase_waves_change_no_result(pkg, data):
     a, b = runs[True], runs[False]
     assert [r_["gamma_new"] for r_ in a["records"]] == [r_["gamma_new"] for r_ in b["records"]]
     assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# A10 on the device: batches of Metropolis iterations with one host synchronisation (smc_mh_sweeps_device_rng)
+# ---------------------------------------------------------------------------------------------------
+def _same_run(a, b):
+    assert a["gamma"] == b["gamma"] == 1.0 and a["step"] == b["step"]
+    for ra, rb in zip(a["records"], b["records"]):
+        assert ra["gamma_new"] == rb["gamma_new"] and ra["last_j"] == rb["last_j"] and ra["n_accept"] == rb["n_accept"]
+        assert len(ra["mh"]) == len(rb["mh"]) == ra["last_j"] + 1
+        for ma, mb in zip(ra["mh"], rb["mh"]):
+            assert ma["mhstep_ratio"] == mb["mhstep_ratio"] and ma["accepted_now"] == mb["accepted_now"]
+            assert ma["accepted_ever"] == mb["accepted_ever"] and np.array_equal(ma["cov_m"], mb["cov_m"])
+    assert np.array_equal(a["p_pred"], b["p_pred"]) and np.array_equal(a["lk"], b["lk"]) and a["logZ"] == b["logZ"]
+    assert a["stats"]["mutation_sweeps"] == b["stats"]["mutation_sweeps"]
+
+
+@pytest.mark.parametrize("n,wide", [(20000, False), (200000, False), (20000, True)])
+def test_device_side_mh_loop_control_is_bit_identical(pkg, data, n, wide):
+    """VERDICT r3 item 3.  The Metropolis loop of a tempering step (Micmem_SMC_main.py:209-249) with its control on the device
+    - iterations enqueued back to back, break / halving decided by the control kernel, one synchronisation per batch - against
+    the loop with one call and one Python decision per iteration (mh_batch = 0): schedule, loop lengths, every iteration's
+    cov_m, mhstep_ratio and accept counts, final particles, likelihoods and evidence bit-identical, whatever the batch size
+    (1: a decision per synchronisation as before but taken on the device; 3: batches that end mid-loop and are continued;
+    "auto"; 32: the whole loop speculated, most of its sweeps finding the loop ended).  `wide`: proposals far too wide
+    (mhstep_factor 40), so that r_ac.sum() < r_threshold_min * N and the halving branch (:247-249) runs on the device too."""
+    kw = dict(mhstep_factor=40.0, mhstep_factor_cov=40.0) if wide else {}
+    runs = {}
+    for mb in (0, 1, 3, "auto", 32):
+        with make_engine(pkg, data, n) as eng:
+            runs[mb] = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n, mh_batch=mb, **kw), rng="device", verbose=False, seed_device=7)
+    ref = runs[0]
+    for mb in (1, 3, "auto", 32):
+        _same_run(ref, runs[mb])
+    steps, sweeps = ref["step"], ref["stats"]["mutation_sweeps"]
+    assert ref["stats"]["mh_syncs"] == sweeps and runs[1]["stats"]["mh_syncs"] == sweeps
+    assert runs[32]["stats"]["mh_syncs"] == steps                       # ONE synchronisation per tempering step
+    assert runs[32]["stats"]["mh_noop_sweeps"] > 0 == ref["stats"]["mh_noop_sweeps"]
+    assert steps <= runs["auto"]["stats"]["mh_syncs"] < sweeps
+    if wide:
+        ratios = [m["mhstep_ratio"] for r in ref["records"] for m in r["mh"]]
+        assert min(ratios) < 1.0                                        # the halving branch was taken
+
+
+def test_mh_batch_entry_point_logs_and_limits(pkg, data):
+    """smc_mh_sweeps_device_rng on its own: thresholds that can never trigger -> all n_iter iterations run, not stopped,
+    ratio unchanged; a stop threshold of 0 -> exactly one iteration runs, the rest find the loop ended and leave p_filt,
+    lk1, the accept flags and the carried moments alone (a following per-iteration call continues as if they had never been
+    enqueued); bad arguments are refused."""
+    n = 30000
+    s = pkg.SMCSettings(n_particle=n)
+    w_cov = s.w_cov()
+    th = mixed_particles(n, seed=4)
+
+    def fresh():
+        eng = make_engine(pkg, data, n)
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        eng.loglik(pkg.SMC_SET_PRED)
+        eng.upload_particles(pkg.SMC_SET_FILT, th)
+        eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+        return eng
+    with fresh() as a, fresh() as b:
+        ref = [a.mh_iteration_device_rng(0.3, 1.0, w_cov, 5, (2 << 16) | j, 0) for j in range(4)]
+        out = b.mh_sweeps_device_rng(0.3, 1.0, w_cov, 5, 2 << 16, 4, 1e300, -1.0, 0)
+        assert out["n_done"] == 4 and not out["stopped"] and out["ratio_next"] == 1.0
+        for r, it in zip(ref, out["iterations"]):
+            assert r["accepted_now"] == it["accepted_now"] and r["accepted_ever"] == it["accepted_ever"]
+            assert np.array_equal(r["cov_m"], it["cov_m"]) and it["mhstep_ratio"] == 1.0 and it["n_failed"] == 0
+        assert np.array_equal(a.download_particles(pkg.SMC_SET_FILT), b.download_particles(pkg.SMC_SET_FILT))
+        assert np.array_equal(a.download_lk(pkg.SMC_SET_FILT), b.download_lk(pkg.SMC_SET_FILT))
+        assert np.array_equal(a.download_accept_flags(), b.download_accept_flags())
+    with fresh() as a, fresh() as b:
+        ref = [a.mh_iteration_device_rng(0.3, 1.0, w_cov, 5, (2 << 16) | j, 0) for j in range(2)]
+        out = b.mh_sweeps_device_rng(0.3, 1.0, w_cov, 5, 2 << 16, 6, 0.0, -1.0, 0)      # any accepted particle ends the loop
+        assert out["n_done"] == 1 and out["stopped"] and len(out["iterations"]) == 1
+        assert out["iterations"][0]["accepted_ever"] == ref[0]["accepted_ever"] > 0
+        nxt = b.mh_iteration_device_rng(0.3, 1.0, w_cov, 5, (2 << 16) | 1, 0)            # the carried moments are intact
+        assert nxt["accepted_now"] == ref[1]["accepted_now"] and np.array_equal(nxt["cov_m"], ref[1]["cov_m"])
+        assert np.array_equal(a.download_particles(pkg.SMC_SET_FILT), b.download_particles(pkg.SMC_SET_FILT))
+        halved = b.mh_sweeps_device_rng(0.3, 1.0, w_cov, 5, (2 << 16) | 2, 3, 1e300, 1e300, 0)   # every count is "too small"
+        assert halved["n_done"] == 3 and [it["mhstep_ratio"] for it in halved["iterations"]] == [1.0, 0.5, 0.25]
+        assert halved["ratio_next"] == 0.125
+        with pytest.raises(pkg.SmcError):
+            b.mh_sweeps_device_rng(0.3, 1.0, w_cov, 5, 0, 33, 0.0, 0.0, 0)
+        with pytest.raises(pkg.SmcError):
+            b.mh_sweeps_device_rng(0.3, 1.0, w_cov, 5, 0, 0, 0.0, 0.0, 0)

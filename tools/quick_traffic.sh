@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err || exit 1
 timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err || exit 1
 cd $R
-python3 tools/pmc_summary.py --out $O/summary.json --fetch-dir $O/pmc_fetch --write-dir $O/pmc_write --particles-per-gpu 1000000 --command quick
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/summary.json --particles-per-gpu 1000000 --command quick
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
 python3 -c "
 import json; d=json.loads(open('$O/bench.json').read().strip().splitlines()[-1]); print('ms_per_step', d['ms_per_step'], 'value %.4g' % d['value'])"
