@@ -452,6 +452,9 @@ def main():
                     help="A/B switch: heterogeneous Metropolis sweeps hand their solves out in index order (SMCSettings.cost_order)")
     ap.add_argument("--no-fast-tail", action="store_true",
                     help="A/B switch: lone chains run the compiled step function, not the hand-written loop (smc_set_fast_tail)")
+    ap.add_argument("--mh-batch", default="auto",
+                    help="Metropolis iterations enqueued per host synchronisation, loop control on the device (SMCSettings.mh_batch): "
+                         "'auto' (default), an integer, or 0 = one call and one host decision per iteration (round 3's loop)")
     ap.add_argument("--progress", action="store_true",
                     help="methanation only: one line per sweep on stderr and in gpurun_out/bench_methanation_progress.log")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -471,8 +474,9 @@ def main():
     n_local = args.particles_per_gpu
     n_global = n_local * world
     t, P_obs, S0 = load_mm_data()
+    mh_batch = args.mh_batch if args.mh_batch == "auto" else int(args.mh_batch)
     s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first, in_phase=not args.no_in_phase,
-                        cost_order=not args.no_cost_order)
+                        cost_order=not args.no_cost_order, mh_batch=mh_batch)
 
     # SMC_BENCH_DEVICE pins every rank to one device (rehearsing the multi-rank path on a one-GPU box)
     dev = int(os.environ.get("SMC_BENCH_DEVICE", local_rank))
@@ -567,6 +571,11 @@ def main():
             "ess_iters_per_s_wall": ess_iters / ess_wall_s if ess_wall_s > 0 else None,
             "ess_iters": ess_iters, "ess_kernel_ms_total": ess_ms, "ess_search_wall_ms_total": 1e3 * ess_wall_s,
             "ess_search_synchronisations": ess_syncs,
+            # host synchronisations of the Metropolis loops (round 3: one per sweep; now the loop control runs on the device and
+            # the host waits once per batch of enqueued sweeps), and the enqueued sweeps that found their loop already ended
+            "mh_loop_synchronisations": sum(o["stats"].get("mh_syncs", 0) for o in outs),
+            "mh_speculative_noop_sweeps": sum(o["stats"].get("mh_noop_sweeps", 0) for o in outs), "mh_batch": mh_batch,
+            "tempering_steps_total": sum(o["step"] for o in outs),
             "tempering_steps_per_run": [o["step"] for o in outs],
             "mutation_sweeps": sweeps, "logZ": [o["logZ"] for o in outs],
             "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(),

@@ -751,11 +751,12 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-// Blocks of the accept kernel: grid-stride, so that counters and moment rows cost one atomic / one row per block.  The cap is
-// what the streaming side needs: 170 B per particle through 7 loads and 5 stores per thread want every CU full of waves
-// (round 3 ran 1024 blocks = 16 waves per CU: 60 us for 10^6 particles, 2.8 TB/s; A/B in profiles/r04_ab_finish_grid.log).
+// Blocks of the accept kernel: grid-stride, so that counters and moment rows cost one atomic / one row per block.  More blocks
+// do NOT help (A/B on one box, whole run of 10^6 particles, profiles/r04_ab_finish_grid.log: 1024 -> 74.6 ms, 2048 -> 75.1,
+// 4096 -> 76.3): the kernel's time goes into the per-block tail - nine 6-step wave reductions of the moments and the counters -
+// not into its 170 B per particle.
 #ifndef SMC_FINISH_GRID_CAP
-#define SMC_FINISH_GRID_CAP 2048
+#define SMC_FINISH_GRID_CAP 1024
 #endif
 static unsigned finish_grid(int64_t n) {
     static const int64_t cap = [] {

@@ -422,7 +422,6 @@ __global__ void mh_transform_kernel(const double *__restrict__ mom, const double
 // the all-reduce that precedes this kernel on the stream: every rank takes the same decision.
 template <int D>
 __global__ void __launch_bounds__(kScanBlock) mh_control_kernel(MHControlArgs a, WCov wcov) {
-    __shared__ double lds[4];
     MHControl *ctl = a.ctl;
     const int t = threadIdx.x;
     if (a.mode & kCtlInit) {
@@ -436,15 +435,32 @@ __global__ void __launch_bounds__(kScanBlock) mh_control_kernel(MHControlArgs a,
     } else if (ctl->stop) {
         return;
     }
-    constexpr int nv = D + D * (D + 1) / 2;
+    constexpr int nv = D + D * (D + 1) / 2;      // == a.nv (the Michaelis-Menten accept kernel writes rows of d + d(d+1)/2 values)
     if (a.mode & kCtlDecide) {
         if (a.rows) {      // one rank: no all-reduce between the accept kernel and this one, so the row reduction happens here
-            for (int v = 0; v < a.nv; ++v) {
-                double s = 0.0;
-                for (int i = t; i < a.n_rows; i += blockDim.x) s += a.rows[(size_t)i * a.nv + v];
-                s = block_sum(s, lds);
-                if (t == 0) a.vec[v] = s;
+            // moments_reduce_kernel's summation order per value - thread t adds rows t, t + 256, ... in turn, the wave sums by
+            // shuffles, the four waves in order - with all nv values of a row (contiguous) taken in one pass over the rows
+            double acc[nv];
+#pragma unroll
+            for (int v = 0; v < nv; ++v) acc[v] = 0.0;
+            for (int i = t; i < a.n_rows; i += blockDim.x) {
+                const double *row = a.rows + (size_t)i * nv;
+#pragma unroll
+                for (int v = 0; v < nv; ++v) acc[v] += row[v];
             }
+            __shared__ double wpart[kScanBlock / 64][nv];
+#pragma unroll
+            for (int v = 0; v < nv; ++v) {
+                const double ws = wave_sum(acc[v]);
+                if ((t & 63) == 0) wpart[t >> 6][v] = ws;
+            }
+            __syncthreads();
+            if (t < nv) {
+                double r = wpart[0][t];
+                for (int q = 1; q < kScanBlock / 64; ++q) r += wpart[q][t];
+                a.vec[t] = r;
+            }
+            __syncthreads();      // thread 0 reads the vector back below
             if (t == 0) {
                 a.vec[a.nv] = (double)a.counters->accepted_now;
                 a.vec[a.nv + 1] = (double)a.counters->accepted_ever;

@@ -481,8 +481,8 @@ def test_sharded_methanation_run_equals_single_rank(pkg, M, cond_guess, world):
     generic_accept_kernel / meth_certainly_rejected (global_offset = rank * n_local), and the per-rank misfit order of the
     experiments (every rank orders by its own block's statistics - any order must give the same results).
     Device-RNG mode is keyed by the global index, so the sharded run must reproduce the one-rank run: tempering schedule,
-    Metropolis lengths, accept counts and offspring counts exactly; particles and evidence to 1e-9 (the cross-rank moment
-    sums round differently from one block's tree, so proposals may differ in the last bits)."""
+    Metropolis lengths, accept counts and offspring counts exactly; particles and evidence to 1e-9, likelihoods to 1e-6 (the
+    cross-rank moment sums round differently from one block's tree, so proposals may differ in the last bits)."""
     cond, guess = cond_guess
     np.random.seed(20250205)
     flows0, _, _ = M.my_model(M.BASEPARAMS, cond, guess)
@@ -502,7 +502,10 @@ def test_sharded_methanation_run_equals_single_rank(pkg, M, cond_guess, world):
     lk = np.concatenate([o["lk"] for o in outs])
     assert p.shape == ref["p_pred"].shape
     assert (np.abs(p - ref["p_pred"]) / np.maximum(1.0, np.abs(ref["p_pred"]))).max() < 1e-9
-    assert (np.abs(lk - ref["lk"]) / np.maximum(1.0, np.abs(ref["lk"]))).max() < 1e-9
+    # likelihoods: 1e-6 relative.  A proposal that differs in its last bit can change one accept / reject decision of the BDF step
+    # controller, which moves the outlet flows by a fraction of the integrator's tolerance (rtol = atol = 1e-6): observed 1.1e-7
+    # relative on logL ~ -320, and none of these differences flipped a Metropolis decision (the counts above are exact)
+    assert (np.abs(lk - ref["lk"]) / np.maximum(1.0, np.abs(ref["lk"]))).max() < 1e-6
     # every rank solved (or cancelled) exactly its own block's items in every sweep: the library's own check passed in each
     # sweep (smc_meth_sweep_check), and the blocks' solve counts add up to the one-rank run's
     tot = sum(o["stats"]["dae_solves"] + o["stats"]["dae_solves_cancelled"] for o in outs)

@@ -1282,37 +1282,47 @@ def test_cost_ordered_handout_changes_no_result(pkg, data, n):
 
 
 def test_cost_ordered_handout_solves_in_support_proposals_without_a_cost_ratio(pkg, data):
-    """under a normal prior on Km every proposal is in the support, also those with Km <= 0 - which have no
-    Vmax / Km cost ratio.  They used to share the counting sort's last class with the out-of-support proposals, which the
-    solve kernel never visits: nobody wrote their sums (early rejection on: NaN -> a poisoned lk1; off: the previous sweep's
-    stale sums fed the accept test).  With the fix they sit in a real class and are solved like any other: four fused
-    iterations with the cost order on and off give the same accept counts, the same FAILURE counts (most of these solves run
-    into the pole S = -Km and fail, as SciPy's would), particles and likelihoods."""
+    """under a normal prior on Km a proposal with Km <= 0 is in the support - but has no Vmax / Km cost ratio.  It used
+    to share the counting sort's last class with the out-of-support proposals, which the solve kernel never visits: nobody wrote
+    its sums (early rejection on: the pending NaN became lk2 and NaN * 0 + lk1 poisoned lk1; off: the previous sweep's stale sums
+    fed the accept test).  With the fix it sits in a real class and is solved like any other.
+    The case is made deterministic with Km == 0 exactly (dS/dt = -Vmax: a benign ODE that every path of the kernel integrates
+    alike; for Km < 0 the solution runs into the pole S = -Km and what a solver returns there depends on its last bits): an
+    eighth of the particles has Km = 0 and w_cov carries no Km variance, so their proposals keep it.  Four fused iterations with
+    the cost order on and off: accept counts, failure counts, particles and likelihoods identical, nothing poisoned."""
     n = 32768
     priors = {"Vmax": {"dist": "uniform", "low": 0, "high": 10}, "Km": {"dist": "normal", "mu": 0.05, "sigma": 0.2},
               "sigma": {"dist": "uniform", "low": 0, "high": 10}}
     s = pkg.SMCSettings(n_particle=n, priors=priors)
     w_cov = s.w_cov()
+    w_cov[1, :] = 0.0
+    w_cov[:, 1] = 0.0
     rs = np.random.RandomState(21)
-    th = np.column_stack([rs.uniform(0.5, 3.0, n), rs.uniform(0.01, 0.12, n), rs.uniform(0.01, 0.5, n)])
+    th = np.column_stack([rs.uniform(0.5, 3.0, n), rs.uniform(0.01, 0.12, n), rs.uniform(0.5, 3.0, n)])
+    th[: n // 8, 1] = 0.0
     res = {}
     for on in (True, False):
         with make_engine(pkg, data, n, priors=priors) as eng:
             eng.set_cost_order(on)
             eng.upload_particles(pkg.SMC_SET_PRED, th)
             assert eng.loglik(pkg.SMC_SET_PRED)["n_failed"] == 0
+            lk0 = eng.download_lk(pkg.SMC_SET_PRED)
+            assert np.isfinite(lk0).all()
             eng.upload_particles(pkg.SMC_SET_FILT, th)
-            eng.upload_lk(pkg.SMC_SET_FILT, eng.download_lk(pkg.SMC_SET_PRED))
+            eng.upload_lk(pkg.SMC_SET_FILT, lk0)
             outs, props = [], []
             for j in range(4):
-                outs.append(eng.mh_iteration_device_rng(0.01, 1.0, w_cov, 13, (5 << 16) | j, 0))
+                outs.append(eng.mh_iteration_device_rng(0.05, 1.0, w_cov, 13, (5 << 16) | j, 0))
                 props.append(eng.download_particles(pkg.SMC_SET_PRED))
             res[on] = ([o["accepted_now"] for o in outs], [o["n_failed"] for o in outs], eng.download_particles(pkg.SMC_SET_FILT),
                        eng.download_lk(pkg.SMC_SET_FILT), props)
-    assert (res[True][4][0][:, 1] <= 0).sum() > n // 50          # the case is really there: proposals with Km <= 0 ...
-    assert res[True][0] == res[False][0] and res[True][1] == res[False][1]
-    assert np.array_equal(res[True][2], res[False][2]) and np.array_equal(res[True][3], res[False][3], equal_nan=True)
-    assert np.isfinite(res[True][3]).all()                        # ... and none of them ever poisoned a stored likelihood
+    zero_km = res[True][4][0][:, 1] == 0.0
+    assert zero_km.sum() == n // 8                                 # the case is really there: in-support proposals with Km == 0 ...
+    assert (res[True][4][0][zero_km, 0] != th[zero_km, 0]).mean() > 0.5     # ... most of which moved (were not reset to the current point)
+    assert res[True][0] == res[False][0] and res[True][1] == res[False][1] == [0, 0, 0, 0]
+    assert np.array_equal(res[True][2], res[False][2]) and np.array_equal(res[True][3], res[False][3])
+    assert np.isfinite(res[True][3]).all()                         # ... none of which ever poisoned a stored likelihood
+    assert (res[True][2][: n // 8, 0] != th[: n // 8, 0]).sum() > n // 100      # and some of them were accepted
 
 
 def test_item_records_of_a_sweep_add_up_to_its_counters(pkg, data):
