@@ -112,19 +112,63 @@ def cpu_baseline(sample_seconds_target=15.0):
             "ess_iters_per_s_n1e6_1core": 1.0 / dt_e}
 
 
+def cpu_baseline_methanation(pkg, cond, guess, sample_seconds_target=15.0):
+    """Config 4's CPU leg (missing 3).  The reference's per-particle path is cal_parallel_new -> my_model: 30 IDA
+    solves of the 357-state DAE per particle, one Ray task per particle (methanation_functions.py:44-92).  Assimulo / SUNDIALS
+    are absent here and on this box, so what is timed is the checker's integrator of the same class on the same equations
+    (`kind: "port"`: oracle/meth_dae_oracle.c - variable-order BDF, finite-difference Jacobian, pivoted banded LU; K8's checker,
+    parity-unpinned like K8 itself) on all host cores: one thread per core, each solving whole (particle, experiment) items -
+    a bounded sample of posterior-like particles x the 30 experiments.  One particle-mutation-step = 30 solves."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import methanation as OM                  # test infrastructure: this leg only (never the product path)
+    M = pkg.methanation
+    cores = effective_cpus()
+    per_core_rate = 9.0                                   # solves/s/core (sizes the sample only)
+    n_part = int(max(2, min(64, round(per_core_rate * cores * sample_seconds_target / 30.0))))
+    rs = np.random.RandomState(0)
+    L = OM._dae_lib()
+    items = []
+    for k in range(n_part):
+        pr = M.BASEPARAMS * (1.0 + 0.02 * rs.standard_normal(len(M.BASEPARAMS)))       # posterior-like: within 2 % of the generating values
+        for i in range(30):
+            items.append((np.ascontiguousarray(guess[i], dtype=np.float64), OM.p0_tuple(cond, i, pr)))
+
+    def solve(it):
+        y0, p = it
+        f, yf, st = np.empty(5), np.empty(357), OM.DaeStats()
+        L.meth_model_one(OM._p(y0), OM._p(p), OM.S_AREA, OM.P_STP, OM._p(f), OM._p(yf), ctypes.byref(st))     # releases the GIL
+        return st.status, st.steps
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        res = list(ex.map(solve, items))
+    dt = time.perf_counter() - t0
+    return {"value": n_part / dt, "unit": "particle-mutation-steps/s", "cores": cores, "kind": "port",
+            "dae_solves_per_s": len(items) / dt, "failed_solves": int(sum(1 for r in res if r[0] != 0)),
+            "bdf_steps_per_solve": float(np.mean([r[1] for r in res])),
+            "sample": f"{n_part} posterior-like particles x 30 experiments = {len(items)} DAE solves (357 states, t = 0..75) by the "
+                      f"checker's BDF integrator (oracle/meth_dae_oracle.c: same class, equations and tolerances as K8; the "
+                      f"reference's IDA is not in the image), {cores} threads, {dt:.1f} s"}
+
+
 # the translation unit of the Michaelis-Menten kernels: mm_kernels.hip and everything it includes
 MM_KERNEL_SOURCES = ("csrc/mm_kernels.hip", "csrc/mm_rk45.h", "csrc/rk45_math.h", "csrc/pow_fifth_exact.h", "csrc/solve_sched.h",
                      "csrc/sweep_args.h", "csrc/philox.h", "csrc/prior.h", "csrc/smc_internal.h", "include/smc_hip.h")
 
 
-def kernel_source_sha(root=None):
-    """sha256 over the CODE the Michaelis-Menten kernels are compiled from (MM_KERNEL_SOURCES; comments and white space
+# ... and of K8, the methanation DAE kernel (meth_smc.hip and everything it includes)
+K8_KERNEL_SOURCES = ("csrc/meth_smc.hip", "csrc/meth_dae_elem.h", "csrc/meth_dae_wave.h", "csrc/meth_dae.h", "csrc/meth_model.h",
+                     "csrc/sweep_args.h", "csrc/philox.h", "csrc/prior.h", "csrc/smc_internal.h", "include/smc_hip.h")
+
+
+def kernel_source_sha(root=None, family="mm"):
+    """sha256 over the CODE a kernel family is compiled from (MM_KERNEL_SOURCES / K8_KERNEL_SOURCES; comments and white space
     stripped, so that editing a comment does not pretend to be a new kernel): ties a profile
     (profiles/*pmc*summary.json) to a kernel revision."""
     import re
     root = root or ROOT
     h = hashlib.sha256()
-    for rel in MM_KERNEL_SOURCES:
+    for rel in (K8_KERNEL_SOURCES if family == "k8" else MM_KERNEL_SOURCES):
         f = os.path.join(root, rel) if rel.startswith("include/") else os.path.join(root, os.path.basename(entry.PKG_DIR), rel)
         txt = open(f, encoding="utf-8", errors="replace").read()
         txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)          # block comments
@@ -157,25 +201,41 @@ def measured_valu_issue(n_local):
         return None, f"{os.path.basename(f)}: {e!r}"
 
 
-def measured_traffic(kernel, n_local):
+def measured_fp64_peak():
+    """FP64 FMA throughput a kernel of nothing but independent v_fma_f64 reaches on an MI355X of this pool, from the newest
+    committed log of tools/fp64_peak.hip (profiles/rNN_fp64_fma_peak.json); (None, why) without one."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fp64_fma_peak.json")))
+    if not files:
+        return None, "no profiles/r*_fp64_fma_peak.json (tools/fp64_peak.hip has not been run)"
+    try:
+        d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+        return float(d["fp64_fma_tflops"]), f"tools/fp64_peak.hip on {d.get('device')} ({os.path.basename(files[-1])})"
+    except (KeyError, ValueError, OSError, IndexError) as e:
+        return None, f"{os.path.basename(files[-1])}: {e!r}"
+
+
+def measured_traffic(kernel, n_local, family="mm"):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (tools/pmc_summary.py), but only
     if that profile was taken on THIS kernel revision at THIS population size; otherwise (None, why)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_summary.json")))
+    pattern = "r*_k8_pmc_fetch_write_summary.json" if family == "k8" else "r*_pmc_fetch_write_summary.json"
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", pattern)) if family == "k8" or "_k8_" not in os.path.basename(f))
     if not files:
         return None, "no PMC summary under profiles/"
     f = files[-1]
     try:
         pmc = json.load(open(f))
         meta = pmc.get("meta", {})
-        if meta.get("kernel_source_sha") != kernel_source_sha():
+        if meta.get("kernel_source_sha") != kernel_source_sha(family=family):
             return None, f"{os.path.basename(f)} was taken on another kernel revision ({meta.get('kernel_source_sha')})"
         if int(meta.get("particles_per_gpu", -1)) != int(n_local):
             return None, f"{os.path.basename(f)} was taken at {meta.get('particles_per_gpu')} particles per GPU"
         # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes fetched (MI355X_MICROARCH.md,
         # HBM section; confirmed on mm_propose_kernel in round 1: 11.8 MiB reported for 24 MB read)
-        b = (2 * pmc["pmc_fetch"][kernel]["avg_counter_value"] + pmc["pmc_write"][kernel]["avg_counter_value"]) * 1024
+        kf = next(k for k in pmc["pmc_fetch"] if kernel in k)       # names as rocprofv3 prints them ("void smc::...<...>", or without "void")
+        kw = next(k for k in pmc["pmc_write"] if kernel in k)
+        b = (2 * pmc["pmc_fetch"][kf]["avg_counter_value"] + pmc["pmc_write"][kw]["avg_counter_value"]) * 1024
         return b, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `{meta.get('command')}` ({os.path.basename(f)}), FETCH_SIZE doubled"
-    except (KeyError, ValueError, OSError) as e:
+    except (KeyError, ValueError, OSError, StopIteration) as e:
         return None, f"{os.path.basename(f)}: {e!r}"
 
 
@@ -202,7 +262,7 @@ def bootstrap_via_file(rank):
                 fh.write(uid)
             os.replace(tmp, path)
             return uid
-        t_end = time.time() + 300
+        t_end = time.time() + COMM_INIT_TIMEOUT_S
         while time.time() < t_end:
             try:
                 data = open(path, "rb").read()
@@ -211,15 +271,42 @@ def bootstrap_via_file(rank):
             except OSError:
                 pass
             time.sleep(0.05)
-        raise RuntimeError(f"rank {rank}: no unique id at {path} after 300 s")
+        raise RuntimeError(f"rank {rank}: no unique id at {path} after {COMM_INIT_TIMEOUT_S:.0f} s")
     return bootstrap
+
+
+COMM_INIT_TIMEOUT_S = float(os.environ.get("SMC_BENCH_INIT_TIMEOUT", "120"))
+
+
+class init_watchdog:
+    """A rank that has not got through the rendezvous + ncclCommInitRank within COMM_INIT_TIMEOUT_S leaves with status 4 (a
+    fresh exit of this process - nothing is re-executed): a peer that never arrives would otherwise keep every other rank
+    waiting inside RCCL for ever, and the launcher (launch_ranks / torch.distributed.run) then ends the others."""
+
+    def __init__(self, rank, what):
+        import threading
+        self.t = threading.Timer(COMM_INIT_TIMEOUT_S, self._fire)
+        self.t.daemon = True
+        self.rank, self.what = rank, what
+
+    def _fire(self):
+        print(f"bench.py: rank {self.rank} did not finish {self.what} within {COMM_INIT_TIMEOUT_S:.0f} s; leaving", file=sys.stderr, flush=True)
+        os._exit(4)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.t.cancel()
 
 
 def make_comm(pkg, eng, rank, world):
     """SingleComm, or the engine's RCCL communicator."""
     if world == 1:
         return pkg.SingleComm()
-    return pkg.RcclComm(eng, rank, world, bootstrap_via_file(rank))
+    with init_watchdog(rank, "the RCCL rendezvous (smc_comm_init)"):
+        return pkg.RcclComm(eng, rank, world, bootstrap_via_file(rank))
 
 
 def launch_ranks(n):
@@ -266,8 +353,12 @@ def launch_check(rank, world):
     fail_rank = os.environ.get("SMC_BENCH_FAIL_RANK")
     if fail_rank is not None and int(fail_rank) == rank:
         sys.exit(3)
-    uid = os.urandom(128) if rank == 0 else None
-    got = bootstrap_via_file(rank)(uid)
+    stall_rank = os.environ.get("SMC_BENCH_STALL_RANK")     # rehearsal of a rank that hangs before the rendezvous
+    with init_watchdog(rank, "the rendezvous"):
+        if stall_rank is not None and int(stall_rank) == rank:
+            time.sleep(3600)                                 # the watchdog ends this rank with status 4
+        uid = os.urandom(128) if rank == 0 else None
+        got = bootstrap_via_file(rank)(uid)
     assert len(got) == 128
     with open(os.path.join(rendezvous_dir(), f"seen_{rank}"), "w") as fh:
         fh.write(hashlib.sha256(got).hexdigest())
@@ -358,6 +449,10 @@ def bench_methanation(args):
     cancelled = sum(o["stats"].get("dae_solves_cancelled", 0) for o in outs)          # ... and skipped by exact early rejection
     k8 = {k: sum(o["stats"].get(k, 0) for o in outs) for k in ("bdf_steps", "newton_iters", "factorisations", "failed_solves")}
     k8_flop = k8["factorisations"] * FLOP_PER_FACTORISATION + k8["newton_iters"] * FLOP_PER_NEWTON_ITERATION
+    # counter traffic of K8 per launch: only from a PMC summary of THIS kernel revision at THIS population (same rule as the MM line)
+    traffic, traffic_note = measured_traffic("smc::meth_particles_dae_kernel", n, family="k8")
+    k8_launches = max(1, tm["solve"]["launches"])
+    cpu = None if (args.no_cpu_baseline or world != 1) else cpu_baseline_methanation(pkg, cond, guess)
     print(json.dumps({
         "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -375,7 +470,16 @@ def bench_methanation(args):
                      "achieved": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "device_counts": k8, "flop_per_factorisation": FLOP_PER_FACTORISATION,
-                     "flop_per_newton_iteration": FLOP_PER_NEWTON_ITERATION, "traffic": None},
+                     "flop_per_newton_iteration": FLOP_PER_NEWTON_ITERATION, "traffic": traffic, "traffic_note": traffic_note,
+                     "kernel_source_sha": kernel_source_sha(family="k8"), "launches": k8_launches,
+                     "avg_launch_ms": tm["solve"]["ms"] / k8_launches,
+                     "algorithmic_flop_per_launch": k8_flop / k8_launches,
+                     "peak_measured_fp64_fma_tflops": measured_fp64_peak()[0],
+                     # algorithmic HBM bytes of a launch: per solve the 357-value start profile + 10 inlet numbers in, 5 flows +
+                     # status out (~100 B per particle plus the shared tables) - idle, as the counters confirm
+                     "hbm": {"algorithmic_bytes_per_launch": (solves / k8_launches) * (357 * 8 + 10 * 8 + 5 * 8 + 4),
+                             "peak_GBps": HBM_PEAK_GBPS}},
+        **({"cpu_baseline": cpu} if cpu else {}),
     }), flush=True)
     comm.barrier()
     eng.close()
@@ -436,6 +540,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--particles-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--particles-total", type=int, default=0,
+                    help="STRONG scaling: this many particles in total, split evenly over the --gpus ranks (BASELINE.json: '1->8-GPU "
+                         "scaling curve for 10^6 particles'); default 0 = weak scaling with --particles-per-gpu per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["mm", "methanation"], default="mm",
                     help="mm = BASELINE.json's headline configuration (default); methanation = config 4 (one GPU)")
@@ -452,6 +559,10 @@ def main():
                     help="A/B switch: heterogeneous Metropolis sweeps hand their solves out in index order (SMCSettings.cost_order)")
     ap.add_argument("--no-fast-tail", action="store_true",
                     help="A/B switch: lone chains run the compiled step function, not the hand-written loop (smc_set_fast_tail)")
+    ap.add_argument("--exact", action="store_true",
+                    help="run the PARITY arithmetic (smc_set_exact_pow(1): correctly rounded step-controller power, the mode whose "
+                         "results are pinned to the reference to 1e-9 with equal RK45 step sequences) on the same device-RNG "
+                         "workload: the price of bit-parity next to the default line")
     ap.add_argument("--mh-batch", default="auto",
                     help="Metropolis iterations enqueued per host synchronisation, loop control on the device (SMCSettings.mh_batch): "
                          "'auto' (default), an integer, or 0 = one call and one host decision per iteration (round 3's loop)")
@@ -471,12 +582,15 @@ def main():
     args.gpus = world
 
     pkg = entry.load_package()
-    n_local = args.particles_per_gpu
+    strong = args.particles_total > 0
+    if strong and args.particles_total % world:
+        raise SystemExit(f"--particles-total {args.particles_total} is not a multiple of the {world} ranks")
+    n_local = args.particles_total // world if strong else args.particles_per_gpu
     n_global = n_local * world
     t, P_obs, S0 = load_mm_data()
     mh_batch = args.mh_batch if args.mh_batch == "auto" else int(args.mh_batch)
     s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first, in_phase=not args.no_in_phase,
-                        cost_order=not args.no_cost_order, mh_batch=mh_batch)
+                        cost_order=not args.no_cost_order, mh_batch=mh_batch, exact_pow=True if args.exact else None)
 
     # SMC_BENCH_DEVICE pins every rank to one device (rehearsing the multi-rank path on a one-GPU box)
     dev = int(os.environ.get("SMC_BENCH_DEVICE", local_rank))
@@ -500,7 +614,9 @@ def main():
     comm.barrier()
     eng.synchronize()
     elapsed = time.perf_counter() - t0
-    elapsed = float(comm.allreduce_max([elapsed])[0])
+    per_rank_s = np.asarray(comm.allgather([elapsed]), dtype=np.float64).reshape(-1)      # every rank's own clock
+    elapsed = float(per_rank_s.max())
+    rccl = eng.comm_info() if world > 1 else {"count": 0, "user_rank": -1, "device": -1}
     timing = eng.timing_get()
     eng.timing_enable(False)
 
@@ -550,8 +666,8 @@ def main():
         hbm_gbps = HBM_BYTES_PER_PARTICLE_SOLVE * n_local / (solve_ms * 1e-3) / 1e9
         ess_ms = timing["ess"]["ms"]
         # the instantiation a sweep of this size launches (csrc/mm_kernels.hip: kFastTailMaxParticles): <WRITE_PRED, EXACT, FAST>
-        fast = (not args.no_fast_tail) and n_local <= 4_000_000
-        kernel_name = "mm_solve_kernel<false, false, %s>" % ("true" if fast else "false")
+        fast = (not args.no_fast_tail) and n_local <= 4_000_000 and not args.exact
+        kernel_name = "mm_solve_kernel<false, true, false>" if args.exact else "mm_solve_kernel<false, false, %s>" % ("true" if fast else "false")
         traffic, traffic_note = measured_traffic("void smc::" + kernel_name, n_local)
         valu, valu_note = measured_valu_issue(n_local)
         ess_l = timing["ess"]["launches"]
@@ -559,11 +675,16 @@ def main():
         result = {
             "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # what RCCL itself reports (ncclCommCount; 0 = one rank, no communicator) and every rank's own wall time per step
+            "rccl_ranks": rccl["count"], "per_rank_ms_per_step": [1e3 * float(v) / args.steps for v in per_rank_s],
             "config": {"workload": "Michaelis-Menten (6 experiments x 40 points), adaptive tempering + "
                                    "residual-systematic resampling, reference defaults; one step = one full SMC run "
                                    "prior->gamma=1", "particles_per_gpu": n_local, "particles_total": n_global,
-                       "rng": "device Philox4x32-10", "parallelism": f"particle-sharded x{world}"},
+                       "rng": "device Philox4x32-10", "parallelism": f"particle-sharded x{world}",
+                       "arithmetic": "parity mode (smc_set_exact_pow(1): correctly rounded pow(x, -0.2) in the step controller; the "
+                                     "instantiation pinned to the reference)" if args.exact else
+                                     "default (fast inverse fifth root in the step controller; <= 7.6e-8 from parity mode on stiff-band particles)"},
             # ESS-search half of the metric, twice: iterations / time of the ESS kernels alone (HIP events), and iterations /
             # WALL time spent in the search (max(lk) + passes + all-reduce + read-back + the host's decision) - what a
             # caller of the search actually waits for
@@ -589,7 +710,7 @@ def main():
                          "achieved": ach_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_source_sha": kernel_source_sha(), "valu_issue": valu, "valu_issue_note": valu_note,
-                         "peak_measured_fp64_fma_tflops": 57.3,
+                         "peak_measured_fp64_fma_tflops": measured_fp64_peak()[0], "peak_measured_note": measured_fp64_peak()[1],
                          "avg_launch_ms": solve_ms, "launches": sv["launches"], "mh_sweep_avg_ms": mh_ms,
                          "algorithmic_flop_per_launch": flop_per_launch,
                          "hbm": {"algorithmic_bytes_per_launch": HBM_BYTES_PER_PARTICLE_SOLVE * n_local,

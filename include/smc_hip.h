@@ -351,6 +351,10 @@ int smc_download_debug_proposals(smc_ctx *ctx, double *aos, double *lk2, uint8_t
 /* unique id = 128 bytes from smc_comm_get_unique_id on rank 0, broadcast by the launcher. */
 int smc_comm_get_unique_id(uint8_t id[128]);
 int smc_comm_init(smc_ctx *ctx, const uint8_t id[128], int rank, int world);
+/* What RCCL itself says about the communicator of this context: ncclCommCount / ncclCommUserRank / ncclCommCuDevice
+ * (count = 0, user_rank = device = -1 when there is none: a single rank needs no communicator).  A launcher can check
+ * that RCCL saw as many ranks as it started. */
+int smc_comm_info(smc_ctx *ctx, int *count, int *user_rank, int *device);
 int smc_comm_allreduce_sum_f64(smc_ctx *ctx, double *inout, int n);
 int smc_comm_allreduce_max_f64(smc_ctx *ctx, double *inout, int n);
 int smc_comm_allreduce_sum_i64(smc_ctx *ctx, int64_t *inout, int n);

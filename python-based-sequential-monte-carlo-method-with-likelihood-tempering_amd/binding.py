@@ -99,6 +99,7 @@ SIGNATURES = {
     "smc_download_debug_proposals": (cint, [c_ctx, c_dp, c_dp, c_u8p, c_u8p, i64]),
     "smc_comm_get_unique_id": (cint, [c_u8p]),
     "smc_comm_init": (cint, [c_ctx, c_u8p, cint, cint]),
+    "smc_comm_info": (cint, [c_ctx, c_ip, c_ip, c_ip]),
     "smc_comm_allreduce_sum_f64": (cint, [c_ctx, c_dp, cint]),
     "smc_comm_allreduce_max_f64": (cint, [c_ctx, c_dp, cint]),
     "smc_comm_allreduce_sum_i64": (cint, [c_ctx, c_i64p, cint]),

@@ -1467,6 +1467,19 @@ int smc_comm_init(smc_ctx *c, const uint8_t id[128], int rank, int world) {
     c->nccl_comm = comm;
     return 0;
 }
+int smc_comm_info(smc_ctx *c, int *count, int *user_rank, int *device) {
+    if (!c) return fail(nullptr, "NULL context");
+    int n = 0, r = -1, dv = -1;
+    if (c->nccl_comm) {
+        NCCLC(c, ncclCommCount((ncclComm_t)c->nccl_comm, &n));
+        NCCLC(c, ncclCommUserRank((ncclComm_t)c->nccl_comm, &r));
+        NCCLC(c, ncclCommCuDevice((ncclComm_t)c->nccl_comm, &dv));
+    }
+    if (count) *count = n;
+    if (user_rank) *user_rank = r;
+    if (device) *device = dv;
+    return 0;
+}
 
 }  // extern "C"
 template <typename T>

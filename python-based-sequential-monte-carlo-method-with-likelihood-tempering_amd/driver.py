@@ -63,6 +63,9 @@ class SMCSettings:
     stiff_first: bool = True          # hand the predictably long solves out first (same results; HipEngine.set_stiff_first)
     in_phase: bool = True             # homogeneous Metropolis sweeps run their waves in phase (same results; HipEngine.set_in_phase)
     cost_order: bool = True           # heterogeneous ones hand their solves out by cost class, in phase (same results; set_cost_order)
+    exact_pow: object = None          # step controller of the RK45 kernels: None = parity arithmetic (correctly rounded pow(x, -0.2), the
+                                      # mode pinned to 1e-9 / equal step sequences against the reference) with rng="numpy", the fast
+                                      # inverse fifth root with rng="device"; True / False force one (HipEngine.set_exact_pow)
     mh_batch: object = "auto"         # Metropolis iterations enqueued per host synchronisation, their loop control (main:243-249) on the
                                       # device (HipEngine.mh_sweeps_device_rng; device RNG, Michaelis-Menten): "auto" = as many as the
                                       # previous tempering step needed, an int = that many, 0 = one call and one decision per iteration
@@ -335,7 +338,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
     if hasattr(engine, "set_cost_order"):
         engine.set_cost_order(s.cost_order)
     if hasattr(engine, "set_exact_pow"):           # parity mode (the reference's NumPy stream): libm-grade step-controller power
-        engine.set_exact_pow(rng == "numpy")
+        engine.set_exact_pow(rng == "numpy" if s.exact_pow is None else bool(s.exact_pow))
     start_time = time.perf_counter()
     stats = {"rk_attempts": 0, "rk_attempts_mh": 0, "n_failed": 0, "mutation_sweeps": 0, "ess_iters": 0,
              "ess_launches": 0, "ess_syncs": 0, "ess_search_s": 0.0, "particle_mutation_steps": 0,

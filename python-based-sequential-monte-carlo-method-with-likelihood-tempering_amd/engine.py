@@ -472,6 +472,12 @@ class HipEngine:
         self._ck(self.L.smc_comm_init(self.ctx, buf, int(rank), int(world)), "smc_comm_init")
         self.rank, self.world = int(rank), int(world)
 
+    def comm_info(self):
+        """RCCL's own view of this context's communicator: {"count", "user_rank", "device"} (count 0: none)."""
+        n, r, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        self._ck(self.L.smc_comm_info(self.ctx, ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)), "smc_comm_info")
+        return {"count": n.value, "user_rank": r.value, "device": d.value}
+
     def comm_allreduce_sum_f64(self, x):
         x = _f64(x).copy()
         self._ck(self.L.smc_comm_allreduce_sum_f64(self.ctx, _dp(x), x.size), "smc_comm_allreduce_sum_f64")

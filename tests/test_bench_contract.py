@@ -51,6 +51,17 @@ def test_bench_launcher_propagates_a_failed_rank():
     assert p.returncode == 3 and "the run is void" in p.stderr
 
 
+def test_bench_rank_that_never_reaches_the_rendezvous_ends_the_run():
+    """a rank that does not get through the rendezvous within the time limit exits non-zero by itself (a
+    fresh exit, status 4), and the launcher then ends the ranks that are waiting for it."""
+    env = dict(os.environ, SMC_BENCH_STALL_RANK="1", SMC_BENCH_INIT_TIMEOUT="3")
+    p = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, timeout=120)
+    assert p.returncode == 4 and "did not finish the rendezvous within 3 s" in p.stderr and "the run is void" in p.stderr
+    env = dict(os.environ, SMC_BENCH_STALL_RANK="0", SMC_BENCH_INIT_TIMEOUT="3")      # rank 0 never publishes the id
+    p = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--launch-check"], env=env, timeout=120)
+    assert p.returncode != 0 and "the run is void" in p.stderr
+
+
 def test_bench_under_torch_distributed_run():
     """The contract's launcher for N > 1: ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env."""
     import socket
@@ -81,13 +92,39 @@ def test_roofline_traffic_is_tied_to_kernel_revision_and_population(tmp_path, mo
     (tmp_path / "profiles").mkdir()
     json.dump(prof, open(tmp_path / "profiles" / "r99_pmc_fetch_write_summary.json", "w"))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    monkeypatch.setattr(bench, "kernel_source_sha", lambda root=None: prof["meta"]["kernel_source_sha"])
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda root=None, family="mm": prof["meta"]["kernel_source_sha"])
     b, note = bench.measured_traffic(k, 1000)
     assert b == (2 * 10.0 + 5.0) * 1024 and "r99_pmc" in note
     assert bench.measured_traffic(k, 2000)[0] is None                       # another population size
-    monkeypatch.setattr(bench, "kernel_source_sha", lambda root=None: "somethingelse")
+    # the K8 line (methanation) reads its own summaries, stamped with the hash of ITS sources
+    assert bench.measured_traffic("smc::meth_particles_dae_kernel", 1000, family="k8")[0] is None
+    k8 = dict(prof, pmc_fetch={"smc::meth_particles_dae_kernel": {"avg_counter_value": 3.0}},
+              pmc_write={"smc::meth_particles_dae_kernel": {"avg_counter_value": 1.0}})
+    json.dump(k8, open(tmp_path / "profiles" / "r99_k8_pmc_fetch_write_summary.json", "w"))
+    assert bench.measured_traffic("smc::meth_particles_dae_kernel", 1000, family="k8")[0] == (2 * 3.0 + 1.0) * 1024
+    assert bench.measured_traffic(k, 1000)[0] == (2 * 10.0 + 5.0) * 1024   # ... and the MM line never picks a K8 file
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda root=None, family="mm": "somethingelse")
     b, note = bench.measured_traffic(k, 1000)
     assert b is None and "another kernel revision" in note                  # another kernel build
+
+
+def test_k8_revision_hash_covers_the_dae_sources_only():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.kernel_source_sha(family="k8") != bench.kernel_source_sha(family="mm")
+    assert any("meth_dae_elem.h" in f for f in bench.K8_KERNEL_SOURCES) and not any("mm_rk45" in f for f in bench.K8_KERNEL_SOURCES)
+
+
+def test_measured_fp64_peak_comes_from_a_committed_probe_log(tmp_path, monkeypatch):
+    """the FP64 FMA figure in the bench line is read from the probe's log under profiles/, or is null."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.measured_fp64_peak()[0] is None
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "r98_fp64_fma_peak.json").write_text('{"probe": "fp64_fma_peak", "device": "X", "fp64_fma_tflops": 61.25}\n')
+    v, note = bench.measured_fp64_peak()
+    assert v == 61.25 and "r98_fp64_fma_peak.json" in note
 
 
 def test_kernel_revision_hash_ignores_comments(tmp_path):

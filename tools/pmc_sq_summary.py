@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--kernel", default="mm_solve_kernel")
     ap.add_argument("--last", type=int, default=0, help="only the last N dispatches of the kernel (0 = all)")
     ap.add_argument("--command", default="")
+    ap.add_argument("--family", choices=["mm", "k8"], default="mm", help="which sources the revision hash covers (bench.kernel_source_sha)")
     a = ap.parse_args()
     import bench
     c, durs = {}, []
@@ -68,7 +69,7 @@ def main():
     cyc = c["GRBM_GUI_ACTIVE"] / N_XCD                      # kernel duration in shader clocks
     valu_busy = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (N_SIMD * cyc)
     f64 = c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
-    out = {"meta": {"kernel_source_sha": bench.kernel_source_sha(), "kernel": a.kernel, "dispatches_averaged": n,
+    out = {"meta": {"kernel_source_sha": bench.kernel_source_sha(family=a.family), "kernel": a.kernel, "dispatches_averaged": n,
                     "command": a.command, "vgpr_count": int(vgpr), "grid": int(grid), "workgroup": int(wg),
                     "avg_dispatch_ns": sum(durs) / len(durs)},
            "counters_per_dispatch": c,
@@ -85,7 +86,16 @@ def main():
                "salu_per_valu_instruction": c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"],
                "waves_resident_fraction": 4.0 * c["SQ_WAVE_CYCLES"] / (c["SQ_WAVES"] * cyc),
                "wave_wait_fraction": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+               "lds_per_valu_instruction": c["SQ_INSTS_LDS"] / c["SQ_INSTS_VALU"] if "SQ_INSTS_LDS" in c else None,
+               "valu_instructions_per_dispatch": c["SQ_INSTS_VALU"],
            }}
+    # optional fifth pass (K8): LDS pipeline and wait reasons
+    for k_out, k_in in (("lds_bank_conflict_share_of_lds_active", ("SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS")),
+                        ("lds_active_fraction_of_wave_cycles", ("SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES")),
+                        ("wait_lgkm_fraction_of_wave_cycles", ("SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES")),
+                        ("scalar_active_fraction_of_wave_cycles", ("SQ_ACTIVE_INST_SCA", "SQ_WAVE_CYCLES"))):
+        if all(q in c for q in k_in) and c[k_in[1]]:
+            out["derived"][k_out] = c[k_in[0]] / c[k_in[1]]
     json.dump(out, open(a.out, "w"), indent=1)
     d = out["derived"]
     print(f"{a.kernel}: VALU busy {100 * d['valu_busy_fraction']:.1f} % (issue floor {100 * d['valu_issue_floor_fraction']:.1f} %), "

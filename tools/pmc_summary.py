@@ -44,15 +44,17 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--particles-per-gpu", type=int, required=True)
     ap.add_argument("--command", default="")
+    ap.add_argument("--family", choices=["mm", "k8"], default="mm", help="which sources the revision hash covers (bench.kernel_source_sha)")
+    ap.add_argument("--kernel", default="mm_solve_kernel", help="kernel whose traffic is printed")
     a = ap.parse_args()
     import bench
-    out = {"meta": {"kernel_source_sha": bench.kernel_source_sha(), "particles_per_gpu": a.particles_per_gpu,
+    out = {"meta": {"kernel_source_sha": bench.kernel_source_sha(family=a.family), "particles_per_gpu": a.particles_per_gpu,
                     "command": a.command, "unit": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE); on gfx950 FETCH_SIZE "
                                                   "reports half of the bytes fetched (MI355X_MICROARCH.md, HBM section)"},
            "pmc_fetch": per_kernel(a.fetch_dir, "FETCH_SIZE"), "pmc_write": per_kernel(a.write_dir, "WRITE_SIZE")}
     json.dump(out, open(a.out, "w"), indent=1)
     for k in sorted(out["pmc_fetch"]):
-        if "mm_solve_kernel" not in k or k not in out["pmc_write"]:
+        if a.kernel not in k or k not in out["pmc_write"]:
             continue
         b = (2 * out["pmc_fetch"][k]["avg_counter_value"] + out["pmc_write"][k]["avg_counter_value"]) * 1024
         print(f"{k}: {b / 1e6:.1f} MB of HBM traffic per launch ({out['pmc_fetch'][k]['dispatches']} dispatches); "
