@@ -563,6 +563,8 @@ def main():
                     help="run the PARITY arithmetic (smc_set_exact_pow(1): correctly rounded step-controller power, the mode whose "
                          "results are pinned to the reference to 1e-9 with equal RK45 step sequences) on the same device-RNG "
                          "workload: the price of bit-parity next to the default line")
+    ap.add_argument("--no-defer-resample", action="store_true", help="A/B switch: resampling with its two host synchronisations (SMCSettings.defer_resample)")
+    ap.add_argument("--no-pinned-results", action="store_true", help="A/B switch: final particles into pageable NumPy arrays (SMCSettings.pinned_results)")
     ap.add_argument("--mh-batch", default="auto",
                     help="Metropolis iterations enqueued per host synchronisation, loop control on the device (SMCSettings.mh_batch): "
                          "'auto' (default), an integer, or 0 = one call and one host decision per iteration (round 3's loop)")
@@ -590,7 +592,8 @@ def main():
     t, P_obs, S0 = load_mm_data()
     mh_batch = args.mh_batch if args.mh_batch == "auto" else int(args.mh_batch)
     s = pkg.SMCSettings(n_particle=n_global, early_reject=not args.no_early_reject, stiff_first=not args.no_stiff_first, in_phase=not args.no_in_phase,
-                        cost_order=not args.no_cost_order, mh_batch=mh_batch, exact_pow=True if args.exact else None)
+                        cost_order=not args.no_cost_order, mh_batch=mh_batch, exact_pow=True if args.exact else None,
+                        defer_resample=not args.no_defer_resample, pinned_results=not args.no_pinned_results)
 
     # SMC_BENCH_DEVICE pins every rank to one device (rehearsing the multi-rank path on a one-GPU box)
     dev = int(os.environ.get("SMC_BENCH_DEVICE", local_rank))
@@ -610,7 +613,13 @@ def main():
     comm.barrier()
     eng.synchronize()
     t0 = time.perf_counter()
-    outs = [one_run(i) for i in range(args.steps)]
+    outs = []
+    for i in range(args.steps):
+        out = one_run(i)
+        if outs:                      # only the last run's particles are looked at below: let the earlier result arrays go (their
+            outs[-1].pop("p_pred")    # page-locked buffers return to the pool and serve the next run's download)
+            outs[-1].pop("lk")
+        outs.append(out)
     comm.barrier()
     eng.synchronize()
     elapsed = time.perf_counter() - t0

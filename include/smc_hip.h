@@ -28,6 +28,7 @@
 #ifndef SMC_HIP_H
 #define SMC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -285,6 +286,19 @@ int smc_exchange_plan(int world, int rank, int64_t n_local, const int64_t *out_b
  * reference's stale-row case, :178-184, occurs), count_sum = sum of trunc(w*N) (the reference prints N - count_sum as n_tmp). */
 int smc_resample_global(smc_ctx *ctx, double max_lk, double gm, double sum_weight_global, double wrand, int first_step,
                         int64_t *n_offspring, int64_t *count_sum);
+
+/* The same resampling ENQUEUED: with one rank no number of it has to visit the host (the residual prefix of the lower ranks is
+ * zero, the gather kernel reads the offspring total on the device), so the call returns without a synchronisation and the
+ * Metropolis sweeps can be enqueued right behind it.  smc_resample_result - call it after your next synchronisation - returns
+ * the two numbers the driver logs (n_offspring, count_sum as above) and fails if the resampler produced more offspring than
+ * particles (the reference's IndexError, :180).  With several ranks smc_resample_enqueue is smc_resample_global. */
+int smc_resample_enqueue(smc_ctx *ctx, double max_lk, double gm, double sum_weight_global, double wrand, int first_step);
+int smc_resample_result(smc_ctx *ctx, int64_t *n_offspring, int64_t *count_sum);
+
+/* Page-locked host memory for results (process-wide, valid until smc_pinned_free - also after smc_destroy): a download into it
+ * is one DMA transfer; into pageable memory the runtime stages through its own buffers and copies on the host. */
+int smc_pinned_alloc(size_t bytes, void **out);
+int smc_pinned_free(void *p);
 
 /* ---- A6: proposal covariance (np.cov(p_filt.T, bias=True), Micmem_SMC_main.py:212) ---------- */
 /* sums[d] = sum_i theta_i over this rank's SMC_SET_FILT block. */

@@ -81,6 +81,10 @@ SIGNATURES = {
     "smc_ess_partials_global": (cint, [c_ctx, f64, c_dp, cint, c_dp, c_dp]),
     "smc_ess_search_global": (cint, [c_ctx, c_dp, cint, cint, c_dp, c_dp, c_dp]),
     "smc_resample_global": (cint, [c_ctx, f64, f64, f64, f64, cint, c_i64p, c_i64p]),
+    "smc_resample_enqueue": (cint, [c_ctx, f64, f64, f64, f64, cint]),
+    "smc_resample_result": (cint, [c_ctx, c_i64p, c_i64p]),
+    "smc_pinned_alloc": (cint, [ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    "smc_pinned_free": (cint, [ctypes.c_void_p]),
     "smc_mh_iteration_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, i64, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "smc_mh_sweeps_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, cint, f64, f64, i64, c_ip, c_ip, c_dp, c_i64p, c_i64p,
                                         c_i64p, c_i64p, c_dp, c_dp]),

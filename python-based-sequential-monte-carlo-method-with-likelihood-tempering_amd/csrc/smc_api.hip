@@ -177,6 +177,9 @@ int smc_create(smc_ctx **out, int device, int64_t n_local, int64_t n_global, int
     CK(hipMalloc(&c->d_oscan, (size_t)n_local * sizeof(int32_t)));
     CK(hipMalloc(&c->d_blk_r, (size_t)(c->n_tiles + 1) * sizeof(double)));
     CK(hipMalloc(&c->d_blk_c, (size_t)(c->n_tiles + 1) * sizeof(int64_t)));
+    CK(hipMalloc(&c->d_blk_o, (size_t)(c->n_tiles + 1) * sizeof(int64_t)));
+    CK(hipMalloc(&c->d_rs, 2 * sizeof(int64_t)));
+    CK(hipHostMalloc(&c->h_rs, 2 * sizeof(int64_t)));
     CK(hipStreamSynchronize(c->stream));
 #undef CK
     *out = c;
@@ -222,6 +225,9 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_oscan);
     (void)hipFree(c->d_blk_r);
     (void)hipFree(c->d_blk_c);
+    (void)hipFree(c->d_blk_o);
+    (void)hipFree(c->d_rs);
+    if (c->h_rs) (void)hipHostFree(c->h_rs);
     (void)hipFree(c->d_sendbuf);
     (void)hipFree(c->d_recvbuf);
     (void)hipFree(c->dbg_lk2);
@@ -835,7 +841,7 @@ int smc_resample_global(smc_ctx *c, double max_lk, double gm, double sum_weight_
     {
         ScopedTimer tm(c, SMC_T_RESAMPLE);
         launch_resample_phase2(c, max_lk, gm, sum_weight_global, prefix, wrand);
-        HIPC(c, hipMemcpyAsync(c->d_small, c->d_blk_c + c->n_tiles, 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->d_small, c->d_blk_o + c->n_tiles, 8, hipMemcpyDeviceToDevice, c->stream));
     }
     HIPC(c, hipGetLastError());
     if (dev_allgather_words(c, 1)) return 1;
@@ -850,6 +856,64 @@ int smc_resample_global(smc_ctx *c, double max_lk, double gm, double sum_weight_
     if (smc_resample_phase3(c, bases.data(), o_all.data(), first_step)) return 1;
     if (n_offspring) *n_offspring = tot;
     if (count_sum) *count_sum = csum;
+    return 0;
+}
+
+// Micmem_SMC_main.py:147-184 ENQUEUED: with one rank nothing of the resampling needs the host - the residual prefix of the lower
+// ranks is zero, the offspring total stays on the device and the gather kernel reads it there - so the three phases go onto the
+// stream without a synchronisation (smc_resample_global: two) and the Metropolis sweeps can be enqueued right behind them.  The
+// two numbers the driver logs (n_tmp = N - sum trunc(w N), :176; the offspring total) are fetched by smc_resample_result, which
+// the driver calls after its next synchronisation.  Several ranks: the exchange plan needs the counts on the host, so this IS
+// smc_resample_global and the result call returns what it found.
+int smc_resample_enqueue(smc_ctx *c, double max_lk, double gm, double sum_weight_global, double wrand, int first_step) {
+    if (!c) return fail(nullptr, "NULL context");
+    HIPC(c, hipSetDevice(c->device));
+    if (c->world > 1) {
+        int64_t o = 0, cs = 0;
+        if (smc_resample_global(c, max_lk, gm, sum_weight_global, wrand, first_step, &o, &cs)) return 1;
+        c->h_rs[0] = cs;
+        c->h_rs[1] = o;
+        c->rs_pending = 2;
+        return 0;
+    }
+    c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
+    {
+        ScopedTimer tm(c, SMC_T_RESAMPLE);
+        launch_resample_phase1(c, max_lk, gm, sum_weight_global);
+        launch_resample_phase2(c, max_lk, gm, sum_weight_global, 0.0, wrand);
+        launch_resample_gather_all(c, first_step, c->d_rs);
+    }
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpyAsync(c->h_rs, c->d_rs, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    c->rs_pending = 1;
+    return 0;
+}
+int smc_resample_result(smc_ctx *c, int64_t *n_offspring, int64_t *count_sum) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!c->rs_pending) return fail(c, "smc_resample_result: no smc_resample_enqueue before it");
+    HIPC(c, hipSetDevice(c->device));
+    if (c->rs_pending == 1) HIPC(c, hipStreamSynchronize(c->stream));   // as a rule the stream has drained long ago
+    c->rs_pending = 0;
+    if (count_sum) *count_sum = c->h_rs[0];
+    if (n_offspring) *n_offspring = c->h_rs[1];
+    if (c->h_rs[1] > c->n_global)
+        return fail(c, "resampling produced more offspring than particles (the reference raises IndexError, "
+                       "Micmem_SMC_main.py:180)");
+    return 0;
+}
+
+// ---- pinned host buffers for results ------------------------------------------------------------------
+// A download into pageable memory is staged through the runtime's own pinned buffers and a host-side copy (~3 ms for the 32 MB
+// of 10^6 final particles); into memory from here the DMA engine writes directly.  The memory belongs to the process, not to a
+// context: it stays valid after smc_destroy, until smc_pinned_free.
+int smc_pinned_alloc(size_t bytes, void **out) {
+    if (!out || bytes == 0) return fail(nullptr, "smc_pinned_alloc: bad arguments");
+    *out = nullptr;
+    HIPC((smc_ctx *)nullptr, hipHostMalloc(out, bytes));
+    return 0;
+}
+int smc_pinned_free(void *p) {
+    if (p) HIPC((smc_ctx *)nullptr, hipHostFree(p));
     return 0;
 }
 
@@ -882,7 +946,7 @@ int smc_resample_phase2(smc_ctx *c, double max_lk, double gm, double sum_weight_
         launch_resample_phase2(c, max_lk, gm, sum_weight_global, residual_prefix, wrand);
     }
     HIPC(c, hipGetLastError());
-    HIPC(c, hipMemcpyAsync(c->h_small, c->d_blk_c + c->n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipMemcpyAsync(c->h_small, c->d_blk_o + c->n_tiles, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     int64_t o;
     memcpy(&o, c->h_small, sizeof o);

@@ -195,6 +195,9 @@ struct smc_ctx {
     int32_t *d_oscan = nullptr;      // inclusive offspring scan (n_local)
     double *d_blk_r = nullptr;       // per tile: residual sums, then exclusive prefix
     int64_t *d_blk_c = nullptr;      // per tile: integer sums, then exclusive prefix
+    int64_t *d_blk_o = nullptr;      // per tile: offspring totals of phase 2, then exclusive prefix
+    int64_t *d_rs = nullptr, *h_rs = nullptr;   // (sum of trunc(w N), offspring total) of an enqueued resampling; host copy pinned
+    int rs_pending = 0;              // smc_resample_enqueue has left its two numbers for smc_resample_result (1: on the device, 2: in h_rs)
     int64_t n_tiles = 0;
     double *d_sendbuf = nullptr;     // (d+1) x capacity staging for remote offspring
     int64_t sendbuf_cap = 0;

@@ -24,4 +24,5 @@ void launch_offspring_from_scan(smc_ctx *c, int64_t *d_out);
 void launch_resample_gather(smc_ctx *c, int64_t m_lo, int64_t m_hi, double *dst_theta, int64_t dst_stride,
                             double *dst_lk, int64_t dst_off);
 void launch_resample_stale(smc_ctx *c, int64_t lo, int64_t hi, int first_step);
+void launch_resample_gather_all(smc_ctx *c, int first_step, int64_t *d_result);   // one rank: all slots, totals read on the device
 }  // namespace smc

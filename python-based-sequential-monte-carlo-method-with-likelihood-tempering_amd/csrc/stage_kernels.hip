@@ -734,6 +734,40 @@ resample_gather_kernel(const int32_t *__restrict__ oscan, int64_t n, const doubl
     dst_lk[dst_off + k] = src_lk[j];
 }
 
+// ONE rank, no host in the loop: every output slot of the rank in one launch, the number of offspring read from device memory
+// (the tile scan's total) - slots below it gather their ancestor, the others keep what the reference's persistent buffers hold
+// there (:178-184; zeros in the first step).  Thread 0 also leaves (trunc(w N) total, offspring total) where ONE later read-back
+// finds them: the driver looks at them after the Metropolis sweeps that follow, not before.
+__global__ void __launch_bounds__(256)
+resample_gather_all_kernel(const int32_t *__restrict__ oscan, int64_t n, const double *__restrict__ src_theta, int64_t src_stride,
+                           const double *__restrict__ src_lk, int d, const int64_t *__restrict__ count_total,
+                           const int64_t *__restrict__ offspring_total, int first_step, double *__restrict__ dst_theta,
+                           int64_t dst_stride, double *__restrict__ dst_lk, int64_t *__restrict__ result /* [2] */) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = *offspring_total;
+    if (m == 0) {
+        result[0] = *count_total;
+        result[1] = total;
+    }
+    if (m >= n) return;
+    if (m < total) {          // first j with oscan[j] > m
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)oscan[mid] > m)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const int64_t j = lo < n ? lo : n - 1;      // total > n (the reference's IndexError case) is reported by the host afterwards
+        for (int c = 0; c < d; ++c) dst_theta[c * dst_stride + m] = src_theta[c * src_stride + j];
+        dst_lk[m] = src_lk[j];
+    } else {
+        for (int c = 0; c < d; ++c) dst_theta[c * dst_stride + m] = first_step ? 0.0 : src_theta[c * src_stride + m];
+        dst_lk[m] = first_step ? 0.0 : src_lk[m];
+    }
+}
+
 // rows the resampler did not write: what the reference's persistent p_filt / lk1 hold there
 __global__ void resample_stale_rows_kernel(const double *__restrict__ src_theta, int64_t src_stride,
                                            const double *__restrict__ src_lk, int d, int64_t lo, int64_t hi,
@@ -938,12 +972,19 @@ void launch_resample_phase2(smc_ctx *c, double max_lk, double gm, double sum_w, 
         hipLaunchKernelGGL(mn_thresholds_kernel, dim3((unsigned)ntm), dim3(kScanBlock), 0, c->stream, m, c->d_mn_thr,
                            c->d_mn_blk, ntm);
     }
-    // d_blk_c is reused for the per-tile offspring totals
+    // the per-tile offspring totals have their own array: d_blk_c[n_tiles] keeps the sum of trunc(w N) of phase 1
     hipLaunchKernelGGL(resample_offspring_kernel, dim3((unsigned)nt), dim3(kScanBlock), 0, c->stream, P.lk, c->n_local,
-                       a, c->d_blk_r, c->d_oscan, c->d_blk_c);
-    hipLaunchKernelGGL((tile_exclusive_scan_kernel<int64_t>), dim3(1), dim3(kScanBlock), 0, c->stream, c->d_blk_c, nt);
+                       a, c->d_blk_r, c->d_oscan, c->d_blk_o);
+    hipLaunchKernelGGL((tile_exclusive_scan_kernel<int64_t>), dim3(1), dim3(kScanBlock), 0, c->stream, c->d_blk_o, nt);
     hipLaunchKernelGGL(resample_apply_prefix_kernel, dim3((unsigned)nt), dim3(kScanBlock), 0, c->stream, c->d_oscan,
-                       c->n_local, c->d_blk_c);
+                       c->n_local, c->d_blk_o);
+}
+void launch_resample_gather_all(smc_ctx *c, int first_step, int64_t *d_result) {
+    ParticleSet &P = c->set[SMC_SET_PRED];
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    hipLaunchKernelGGL(resample_gather_all_kernel, dim3((unsigned)((c->n_local + 255) / 256)), dim3(256), 0, c->stream, c->d_oscan,
+                       c->n_local, P.theta, P.stride, P.lk, c->dim, c->d_blk_c + c->n_tiles, c->d_blk_o + c->n_tiles, first_step,
+                       F.theta, F.stride, F.lk, d_result);
 }
 void launch_offspring_from_scan(smc_ctx *c, int64_t *d_out) {
     hipLaunchKernelGGL(offspring_from_scan_kernel, dim3((unsigned)((c->n_local + 255) / 256)), dim3(256), 0, c->stream,

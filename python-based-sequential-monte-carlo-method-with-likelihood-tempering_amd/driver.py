@@ -66,6 +66,8 @@ class SMCSettings:
     exact_pow: object = None          # step controller of the RK45 kernels: None = parity arithmetic (correctly rounded pow(x, -0.2), the
                                       # mode pinned to 1e-9 / equal step sequences against the reference) with rng="numpy", the fast
                                       # inverse fifth root with rng="device"; True / False force one (HipEngine.set_exact_pow)
+    defer_resample: bool = True       # enqueue the resampling without a host synchronisation (one rank; HipEngine.resample_enqueue)
+    pinned_results: bool = True       # final particles / likelihoods arrive in page-locked host arrays (HipEngine.download_*(pinned=True))
     mh_batch: object = "auto"         # Metropolis iterations enqueued per host synchronisation, their loop control (main:243-249) on the
                                       # device (HipEngine.mh_sweeps_device_rng; device RNG, Michaelis-Menten): "auto" = as many as the
                                       # previous tempering step needed, an int = that many, 0 = one call and one decision per iteration
@@ -230,10 +232,19 @@ def ess_bisection(engine, comm, gamma_old: float, s: SMCSettings, max_lk: float,
             "iters": state["iters"], "launches": state["launches"], "syncs": 1 + state["launches"], "warning": e <= s.ess_limit}
 
 
-def resample(engine, comm, es: dict, wrand_u: float, s: SMCSettings, first_step: bool):
-    """main:147-184 across ranks: residual sums -> prefix; offspring -> output slot bases; gather/exchange."""
+def resample(engine, comm, es: dict, wrand_u: float, s: SMCSettings, first_step: bool, defer: bool = False):
+    """main:147-184 across ranks: residual sums -> prefix; offspring -> output slot bases; gather/exchange.
+    defer (reductions in the engine only): the resampling is ENQUEUED - with one rank without any synchronisation - and the
+    returned callable delivers the two logged numbers later, after the caller's next synchronisation."""
     inv_Np = 1 / s.n_particle                                                 # Micmem_settings.py:17
     wrand = wrand_u * inv_Np                                                  # :156
+    if defer and _on_device(comm) and getattr(engine, "resample_enqueue", None) is not None:
+        engine.resample_enqueue(es["max_lk"], es["gm"], es["sum_weight"], wrand, first_step)
+
+        def later():
+            r = engine.resample_result()
+            return {"n_offspring": r["n_offspring"], "n_tmp_before": s.n_particle - r["count_sum"]}
+        return later
     if _on_device(comm):                                                      # all three phases + their all-gathers in the engine
         r = engine.resample_global(es["max_lk"], es["gm"], es["sum_weight"], wrand, first_step)
         return {"n_offspring": r["n_offspring"], "n_tmp_before": s.n_particle - r["count_sum"]}
@@ -418,7 +429,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         dlogZ = es["gm"] * max_lk + math.log(es["sum_weight"] / n)
         logZ += dlogZ
         wrand_u = np.random.rand() if rng == "numpy" else host_rng.rand()     # :156
-        rs = resample(engine, comm, es, wrand_u, s, first_step=(step == 1))   # :147-184
+        # :147-184.  Not verbose: enqueued; its two logged numbers are read after the Metropolis loop's synchronisation
+        rs = resample(engine, comm, es, wrand_u, s, first_step=(step == 1), defer=s.defer_resample and not verbose)
         if verbose and rank == 0:
             log("n_tmp:", rs["n_tmp_before"])
         engine.reset_accept_flags()                                           # :187
@@ -502,6 +514,8 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
                 mhstep_ratio = mhstep_ratio * 0.5
                 if verbose and rank == 0:
                     log(mhstep_ratio)
+        if callable(rs):
+            rs = rs()
         engine.commit_filt_to_pred()                                          # :251-252
         if verbose and rank == 0:
             log(f"iteration:{step}, nMH:{j}, Calculation time:{time.perf_counter() - start_time}, ESS:{ess}, "
@@ -525,6 +539,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         final = engine.download_particles(SMC_SET_PRED)
         _dump(dump_dir, "pred/last_p_pred", final, rank, world)
         _dump(dump_dir, "Posterior_Distribution", final, rank, world, header=list(s.priors.keys()))
-    return {"p_pred": engine.download_particles(SMC_SET_PRED), "lk": engine.download_lk(SMC_SET_PRED),
+    pin = {"pinned": True} if (s.pinned_results and getattr(engine, "resample_enqueue", None) is not None) else {}   # HipEngine only
+    return {"p_pred": engine.download_particles(SMC_SET_PRED, **pin), "lk": engine.download_lk(SMC_SET_PRED, **pin),
             "records": records, "logZ": logZ, "gamma": gamma_new, "step": step, "stats": stats,
             "wall_s": time.perf_counter() - start_time}

@@ -25,6 +25,54 @@ def _f64(a, shape=None):
     return a
 
 
+class _PinnedPool:
+    """Page-locked host buffers for downloaded results (include/smc_hip.h: smc_pinned_alloc).  A buffer belongs to the NumPy array
+    that views it and returns to the pool when that array (and every view of it) is garbage-collected; the memory is
+    process-wide, so such an array stays valid after its engine is closed.  Buffers are reused by size: a run's final 24 + 8 MB
+    download costs one DMA transfer each instead of the runtime's staged copy into pageable memory."""
+
+    def __init__(self):
+        self.free = {}          # nbytes -> [ptr, ...]
+
+    def take(self, nbytes):
+        lst = self.free.get(nbytes)
+        if lst:
+            return lst.pop()
+        p = ctypes.c_void_p(0)
+        st = lib().smc_pinned_alloc(ctypes.c_size_t(nbytes), ctypes.byref(p))
+        if st != 0:
+            msg = lib().smc_last_error(None)
+            raise SmcError(f"smc_pinned_alloc: {msg.decode() if msg else 'unknown error'}")
+        return p.value
+
+    def give(self, ptr, nbytes):
+        self.free.setdefault(nbytes, []).append(ptr)
+
+
+_PINNED = _PinnedPool()
+
+
+class _PinnedOwner:
+    """What a pinned result array keeps alive (ndarray.base): gives the buffer back to the pool when the last view is gone."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype = tuple(int(v) for v in shape), np.dtype(dtype)
+        self.nbytes = max(8, int(np.prod(self.shape)) * self.dtype.itemsize)
+        self.ptr = _PINNED.take(self.nbytes)
+        self.__array_interface__ = {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            _PINNED.give(self.ptr, self.nbytes)
+        except Exception:       # interpreter shutdown
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """np.empty in page-locked host memory (see _PinnedPool)."""
+    return np.asarray(_PinnedOwner(shape, dtype))
+
+
 class HipEngine:
     """Device-resident particle sets p_pred/lk and p_filt/lk1 plus the stages that act on them."""
 
@@ -222,9 +270,10 @@ class HipEngine:
         assert aos.ndim == 2 and aos.shape[1] == self.dim
         self._ck(self.L.smc_upload_particles(self.ctx, which, _dp(aos), aos.shape[0]), "smc_upload_particles")
 
-    def download_particles(self, which, n=None):
+    def download_particles(self, which, n=None, pinned=False):
+        """(n, d) particles of set `which`.  pinned: the array lives in page-locked host memory (one DMA transfer; see _PinnedPool)."""
         n = self.n_local if n is None else n
-        out = np.empty((n, self.dim))
+        out = pinned_empty((n, self.dim)) if pinned else np.empty((n, self.dim))
         self._ck(self.L.smc_download_particles(self.ctx, which, _dp(out), n), "smc_download_particles")
         return out
 
@@ -232,9 +281,9 @@ class HipEngine:
         lk = _f64(lk)
         self._ck(self.L.smc_upload_lk(self.ctx, which, _dp(lk), lk.shape[0]), "smc_upload_lk")
 
-    def download_lk(self, which, n=None):
+    def download_lk(self, which, n=None, pinned=False):
         n = self.n_local if n is None else n
-        out = np.empty(n)
+        out = pinned_empty((n,)) if pinned else np.empty(n)
         self._ck(self.L.smc_download_lk(self.ctx, which, _dp(out), n), "smc_download_lk")
         return out
 
@@ -324,6 +373,16 @@ class HipEngine:
         o, cs = ctypes.c_int64(0), ctypes.c_int64(0)
         self._ck(self.L.smc_resample_global(self.ctx, float(max_lk), float(gm), float(sum_w), float(wrand),
                                             int(bool(first_step)), ctypes.byref(o), ctypes.byref(cs)), "smc_resample_global")
+        return {"n_offspring": o.value, "count_sum": cs.value}
+
+    def resample_enqueue(self, max_lk, gm, sum_w, wrand, first_step):
+        """Resampling without a host synchronisation (one rank; include/smc_hip.h: smc_resample_enqueue); resample_result() later."""
+        self._ck(self.L.smc_resample_enqueue(self.ctx, float(max_lk), float(gm), float(sum_w), float(wrand), int(bool(first_step))),
+                 "smc_resample_enqueue")
+
+    def resample_result(self):
+        o, cs = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._ck(self.L.smc_resample_result(self.ctx, ctypes.byref(o), ctypes.byref(cs)), "smc_resample_result")
         return {"n_offspring": o.value, "count_sum": cs.value}
 
     def mh_iteration_device_rng(self, gamma, mhstep_ratio, w_cov, seed, stream, global_offset=0):

@@ -1500,3 +1500,82 @@ def test_mh_batch_entry_point_logs_and_limits(pkg, data):
             b.mh_sweeps_device_rng(0.3, 1.0, w_cov, 5, 0, 33, 0.0, 0.0, 0)
         with pytest.raises(pkg.SmcError):
             b.mh_sweeps_device_rng(0.3, 1.0, w_cov, 5, 0, 0, 0.0, 0.0, 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 4: resampling without a host synchronisation (one rank), page-locked result arrays
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scheme", ["residual_systematic", "systematic", "multinomial"])
+@pytest.mark.parametrize("pattern,first", [("spread", True), ("spread", False), ("underflow_tail", True), ("underflow_tail", False),
+                                           ("one_hot", False)])
+def test_enqueued_resampling_equals_the_synchronous_call(pkg, data, scheme, pattern, first):
+    """smc_resample_enqueue (one rank: the offspring total stays on the device, one gather launch covers every output slot, no
+    synchronisation) against smc_resample_global (two synchronisations, host-side plan) on the same weights: offspring counts,
+    the logged totals and the WHOLE p_filt / lk1 block - gathered rows and the rows nobody writes (zeros in the first step, the
+    previous p_pred rows later, Micmem_SMC_main.py:178-184) - identical, for the three schemes."""
+    n = 5000
+    rs = np.random.RandomState(17)
+    lk = rs.standard_normal(n) * 4.0
+    if pattern == "underflow_tail":
+        lk = -np.arange(n, dtype=float) * 30.0      # almost every weight underflows: fewer offspring than particles is possible
+    elif pattern == "one_hot":
+        lk[:] = -1e6
+        lk[n // 3] = 0.0
+    p_pred = rs.standard_normal((n, 3))
+    mx, gm, u = float(lk.max()), 0.7, 0.318
+    sum_w = float(np.sum(np.exp((lk - mx) * gm)))
+    s = pkg.SMCSettings(n_particle=n, resampling=scheme)
+    es = {"max_lk": mx, "gm": gm, "sum_weight": sum_w}
+    got = {}
+    for defer in (False, True):
+        with make_engine(pkg, data, n) as eng:
+            eng.set_resampling(scheme)
+            eng.upload_particles(pkg.SMC_SET_PRED, p_pred)
+            eng.upload_lk(pkg.SMC_SET_PRED, lk)
+            eng.upload_particles(pkg.SMC_SET_FILT, p_pred[::-1].copy())      # something recognisable where nobody writes
+            eng.upload_lk(pkg.SMC_SET_FILT, lk[::-1].copy())
+            out = pkg.resample(eng, pkg.SingleComm(), es, u, s, first_step=first, defer=defer)
+            if defer:
+                assert callable(out)
+                out = out()
+            got[defer] = (out, eng.download_offspring(), eng.download_particles(pkg.SMC_SET_FILT), eng.download_lk(pkg.SMC_SET_FILT))
+    a, b = got[False], got[True]
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert a[1].sum() == a[0]["n_offspring"] <= n
+
+
+def test_pinned_result_arrays_outlive_their_engine_and_are_reused(pkg, data):
+    """Final particles and likelihoods of run_smc arrive in page-locked host memory (one DMA transfer instead of the runtime's
+    staged copy).  The buffer belongs to the array: it is valid after the engine is gone, equals an ordinary download, and goes
+    back to the pool - to be reused by the next download of that size - only when the array and its views are garbage."""
+    import gc
+    from smc_lt_amd import engine as E
+    n = 20000
+    th = mixed_particles(n, seed=9)
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        a = eng.download_particles(pkg.SMC_SET_PRED, pinned=True)
+        b = eng.download_particles(pkg.SMC_SET_PRED)
+        view = a[100:200]
+        addr = a.__array_interface__["data"][0]
+        c = eng.download_particles(pkg.SMC_SET_PRED, pinned=True)            # a is alive: another buffer
+        assert c.__array_interface__["data"][0] != addr
+    assert np.array_equal(a, th) and np.array_equal(b, th) and np.array_equal(c, th)      # after smc_destroy
+    del a, c
+    gc.collect()
+    assert np.array_equal(view, th[100:200])                                  # the view keeps its buffer
+    assert addr not in E._PINNED.free.get(n * 3 * 8, [])
+    del view
+    gc.collect()
+    assert addr in E._PINNED.free.get(n * 3 * 8, [])
+    with make_engine(pkg, data, n) as eng:
+        eng.upload_particles(pkg.SMC_SET_PRED, th)
+        d = eng.download_particles(pkg.SMC_SET_PRED, pinned=True)
+        assert d.__array_interface__["data"][0] in (addr, ) or len(E._PINNED.free.get(n * 3 * 8, [])) >= 1
+        assert np.array_equal(d, th)
+    out = None
+    with make_engine(pkg, data, n) as eng:
+        out = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n), rng="device", verbose=False, seed_device=2)
+    assert np.isfinite(out["p_pred"]).all() and out["p_pred"].shape == (n, 3) and out["lk"].shape == (n,)
+    out["p_pred"][0, 0] = 1.0                                                 # ordinary writable NumPy arrays
