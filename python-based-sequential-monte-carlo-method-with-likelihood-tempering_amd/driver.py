@@ -539,7 +539,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         final = engine.download_particles(SMC_SET_PRED)
         _dump(dump_dir, "pred/last_p_pred", final, rank, world)
         _dump(dump_dir, "Posterior_Distribution", final, rank, world, header=list(s.priors.keys()))
-    pin = {"pinned": True} if (s.pinned_results and getattr(engine, "resample_enqueue", None) is not None) else {}   # HipEngine only
+    pin = {"pinned": True} if (s.pinned_results and getattr(engine, "pinned_downloads", False)) else {}
     return {"p_pred": engine.download_particles(SMC_SET_PRED, **pin), "lk": engine.download_lk(SMC_SET_PRED, **pin),
             "records": records, "logZ": logZ, "gamma": gamma_new, "step": step, "stats": stats,
             "wall_s": time.perf_counter() - start_time}

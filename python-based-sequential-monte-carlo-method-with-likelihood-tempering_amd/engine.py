@@ -75,6 +75,7 @@ def pinned_empty(shape, dtype=np.float64):
 
 class HipEngine:
     """Device-resident particle sets p_pred/lk and p_filt/lk1 plus the stages that act on them."""
+    pinned_downloads = True     # download_particles / download_lk accept pinned=True (page-locked result arrays)
 
     def __init__(self, n_local: int, dim: int = 3, device: int = 0, n_global: int | None = None):
         self.L = lib()

@@ -82,3 +82,89 @@ def test_fused_search_equals_the_chunked_search(pkg, O, data, spread, gamma_old,
     assert a["syncs"] == 1 + max(0, (a["iters"] - 32 + 31) // 32)
     assert a["warning"] == (spread == 3e9 and limit_itr == 40)
     print(spread, gamma_old, "first passing candidate:", a["iters"], "synchronisations", a["syncs"], "vs", b["syncs"])
+
+
+# ---- Metropolis loop control in batches (round 4): the driver's bookkeeping over a scripted engine ------------------------------
+class _ScriptedEngine(OracleEngine):
+    """OracleEngine + the device-RNG entry points run_smc uses, with the Metropolis sweeps SCRIPTED: sweep number q of the run
+    reports accepted_ever = script[q] * n and changes nothing else.  mh_sweeps_device_rng plays the control kernel in Python
+    (break above thr_stop, halve below thr_halve, enqueued sweeps after the break do not happen) and records every call."""
+    model = ("mm",)
+
+    def __init__(self, O, data, priors, n, script):
+        super().__init__(O, data, priors, n, n, 0, 1)
+        self.script, self.q, self.calls, self.deferred = list(script), 0, [], 0
+
+    def sample_prior_device(self, seed, lo):
+        self.theta[PRED] = np.random.RandomState(seed).uniform(0.05, 3.0, (self.n_local, 3))
+
+    def _one(self, ratio):
+        acc = int(self.script[self.q % len(self.script)] * self.n_local)
+        self.q += 1
+        return {"accepted_now": acc // 2, "accepted_ever": acc, "n_failed": 0, "rk_attempts": 100, "mhstep_ratio": ratio,
+                "cov_m": np.eye(3) * self.q}
+
+    def mh_iteration_device_rng(self, gamma, ratio, w_cov, seed, stream, lo=0):
+        self.calls.append(("iter", stream, 1, ratio))
+        return self._one(ratio)
+
+    def mh_sweeps_device_rng(self, gamma, ratio, w_cov, seed, stream0, k, thr_stop, thr_halve, lo=0):
+        self.calls.append(("batch", stream0, k, ratio))
+        its, stopped = [], False
+        for i in range(k):
+            it = self._one(ratio)
+            its.append(it)
+            if it["accepted_ever"] > thr_stop:
+                stopped = True
+                break
+            if it["accepted_ever"] < thr_halve:
+                ratio = ratio * 0.5
+        return {"n_done": len(its), "stopped": stopped, "ratio_next": ratio, "iterations": its}
+
+    def resample_enqueue(self, *a):
+        self._rs = self.resample_global(*a)
+        self.deferred += 1
+
+    def resample_result(self):
+        return self._rs
+
+
+@pytest.mark.parametrize("mh_batch", [1, 2, "auto", 32])
+def test_batched_metropolis_loop_keeps_the_books_of_the_per_iteration_loop(pkg, O, data, mh_batch):
+    """run_smc with the loop control in the engine (SMCSettings.mh_batch) against the loop with one call and one Python decision
+    per sweep, over the same scripted acceptance: loop lengths (the reference's j), every sweep's ratio and counts, the stream
+    numbers (step << 16 | j) and the statistics agree; the batch sizes follow the documented policy; enqueued sweeps after a
+    break are counted as such; the resampling was enqueued and its numbers read afterwards."""
+    n = 64
+    # acceptance per sweep: low values force halvings and long loops, a value above r_th (0.5; 0.7 at gamma = 1) ends a loop
+    script = [0.05, 0.3, 0.6, 0.2, 0.55, 0.04, 0.08, 0.2, 0.3, 0.9, 0.75, 0.1, 0.8]
+    runs = {}
+    for mb in (0, mh_batch):
+        eng = _ScriptedEngine(O, data, None, n, script)
+        runs[mb] = (pkg.run_smc(eng, pkg.SMCSettings(n_particle=n, mh_batch=mb), rng="device", verbose=False, seed_device=5), eng)
+    (a, ea), (b, eb) = runs[0], runs[mh_batch]
+    assert a["gamma"] == b["gamma"] == 1.0 and a["step"] == b["step"] >= 2
+    for ra, rb in zip(a["records"], b["records"]):
+        assert ra["last_j"] == rb["last_j"] and ra["n_accept"] == rb["n_accept"] and ra["gamma_new"] == rb["gamma_new"]
+        assert ra["n_offspring"] == rb["n_offspring"] == n and ra["n_tmp_before"] == rb["n_tmp_before"]
+        assert [m["mhstep_ratio"] for m in ra["mh"]] == [m["mhstep_ratio"] for m in rb["mh"]]
+        assert [m["accepted_ever"] for m in ra["mh"]] == [m["accepted_ever"] for m in rb["mh"]]
+        assert all(np.array_equal(x["cov_m"], y["cov_m"]) for x, y in zip(ra["mh"], rb["mh"]))
+    sweeps = a["stats"]["mutation_sweeps"]
+    assert b["stats"]["mutation_sweeps"] == sweeps == sum(r["last_j"] + 1 for r in a["records"])
+    assert b["stats"]["particle_mutation_steps"] == sweeps * n and b["stats"]["rk_attempts_mh"] == 100 * sweeps
+    assert a["stats"]["mh_syncs"] == sweeps == len(ea.calls) and a["stats"]["mh_noop_sweeps"] == 0
+    assert b["stats"]["mh_syncs"] == len(eb.calls) <= sweeps
+    assert eb.deferred == b["step"] and ea.deferred == a["step"]
+    # every batch starts at the stream number of its first sweep, (step << 16) | j
+    j, step_no, k_prev = 0, 0, None
+    for kind, stream0, k, ratio in eb.calls:
+        assert kind == "batch"
+        if (stream0 >> 16) != step_no:
+            step_no, j = stream0 >> 16, 0
+        assert stream0 == (step_no << 16) | j
+        j += min(k, (b["records"][step_no - 1]["last_j"] + 1) - j)
+    if mh_batch == 32:
+        assert b["stats"]["mh_syncs"] == b["step"] and b["stats"]["mh_noop_sweeps"] > 0
+    if mh_batch == 1:
+        assert b["stats"]["mh_syncs"] == sweeps and b["stats"]["mh_noop_sweeps"] == 0

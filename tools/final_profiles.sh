@@ -26,7 +26,25 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_
 done
 log "methanation N = 1024 under rocprof"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/meth_stats -o run -- python3 $R/bench.py --workload methanation --particles-per-gpu 1024 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_methanation_n1024_under_rocprof.json 2> $O/meth_stats.err
+# round 4: counter passes on K8 (FETCH / WRITE and six SQ sets), the FP64 FMA probe
+K8CMD="python3 $R/bench.py --workload methanation --particles-per-gpu 1024 --steps 1 --warmup 0 --no-cpu-baseline"
+log "k8 pmc fetch"
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/k8_pmc_fetch -o run -- $K8CMD > /dev/null 2> $O/k8_pmc_fetch.err
+log "k8 pmc write"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/k8_pmc_write -o run -- $K8CMD > /dev/null 2> $O/k8_pmc_write.err
+i=0
+for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_WAVES SQ_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" "SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_INT32 SQ_INSTS_VMEM"; do
+  i=$((i+1))
+  log "k8 sq pass $i"
+  timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/k8_sq$i -- $K8CMD > $O/k8_sq$i.log 2>&1
+done
+log "fp64 probe"
+$R/tools/fp64_peak > $O/fp64_fma_peak.json 2> $O/fp64.err
 cd $R
+log "parity arithmetic (--exact)"
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --exact > $O/bench_mm_exact.json 2> $O/exact.err
+log "round-3 host loop (A/B)"
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --mh-batch 0 --no-defer-resample --no-pinned-results > $O/bench_mm_r3_host_loop.json 2> $O/r3loop.err
 log "no early reject"
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-early-reject > $O/bench_mm_no_early_reject.json 2> $O/ner.err
 log "1e7"
