@@ -191,6 +191,18 @@ class OracleEngine:
         return {"n_offspring": int(o_all.sum()), "count_sum": int(c_all.sum())}
 
 
+    # round 4: the deferred form of the same call (HipEngine.resample_enqueue / resample_result): run_smc enqueues the
+    # resampling and reads its two logged numbers after the Metropolis loop
+    def resample_enqueue(self, max_lk, gm, sum_w, wrand, first_step):
+        self._rs = self.resample_global(max_lk, gm, sum_w, wrand, first_step)
+        self.n_deferred = getattr(self, "n_deferred", 0) + 1
+
+    def resample_result(self):
+        rs, self._rs = self._rs, None
+        assert rs is not None, "resample_result without resample_enqueue"
+        return rs
+
+
 class EngineSideComm:
     """What comm.RcclComm is to the HipEngine: `on_device` tells the driver to use the engine's *_global entry points;
     the remaining host-side collectives (parity mode draws the noise on the host, so its moments still go through the

@@ -41,7 +41,7 @@ def _worker(rank, world, port, n, seed, q, engine_side):
         out = pkg.run_smc(eng, s, comm=comm, rng="numpy", verbose=False)
         q.put((rank, out["p_pred"], out["lk"], [r["gamma_new"] for r in out["records"]],
                [r["n_accept"] for r in out["records"]], [r["last_j"] for r in out["records"]], out["logZ"],
-               [r["n_offspring"] for r in out["records"]]))
+               [r["n_offspring"] for r in out["records"]], getattr(eng, "n_deferred", 0), out["step"]))
     finally:
         dist.destroy_process_group()
 
@@ -73,6 +73,9 @@ def test_two_rank_gloo_run_equals_single_process_oracle(O, data, n, seed, engine
         assert r[5] == [x.last_j for x in ref["records"]]
         assert all(o == n for o in r[7])
         assert abs(r[6] - ref["logZ"]) < 1e-9 * abs(ref["logZ"])
+        # engine-side reductions: every resampling went through the deferred form (enqueue, numbers read after the Metropolis
+        # loop); a host-side communicator composes the three phases itself and defers nothing
+        assert r[8] == (r[9] if engine_side else 0)
     assert np.abs(p_all - ref["p_pred"]).max() < 1e-9
     assert np.max(np.abs(lk_all - ref["lk"]) / np.maximum(1, np.abs(ref["lk"]))) < 1e-9
 
