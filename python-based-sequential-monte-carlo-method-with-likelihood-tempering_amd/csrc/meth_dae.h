@@ -79,33 +79,38 @@ constexpr double Dz = 0.95e-5, Rhos = 5075, Hr = -164940, R = 8.3144589, Cpg = 2
                  Dint = 0.005, U = 68.2480;
 }
 
-// rate law r and its partial derivatives w.r.t. (Ca, Cb, Cc, Cd, T)  (methanation_set_likelihood.py:44-58)
-SMC_HD double rate_and_grad(double T, double Ca, double Cb, double Cc, double Cd, const double *kin, double g[5]) {
+// rate law r and its partial derivatives w.r.t. (Ca, Cb, Cc, Cd, T)  (methanation_set_likelihood.py:44-58).
+// Round 4: an IEEE division is ~13 instructions of a wave that issues one instruction per 4 cycles, and the residual of a Newton
+// iteration held 33 of them (a third of its instructions).  Quotients by the same divisor share ONE reciprocal (iT = 1/T,
+// 1/(q1 q1), 1/(w1 w1) here; 1/dz, 1/T_i, 1/T_{i+-1} in node_eval): 2-3 ulp per term instead of 0.5, against terms that are
+// compared at 1e-6 - the K7 kernels that are pinned to the reference's residual values (meth_model.h) are untouched.
+SMC_HD double rate_and_grad(double T, double iT, double Ca, double Cb, double Cc, double Cd, const double *kin, double g[5]) {
+    constexpr double iR = 1.0 / k::R;
     const double a = k::R * T * 1e-06, da = k::R * 1e-06;
     const double PH2 = Ca * a, PCO2 = Cb * a, PCH4 = Cc * a, PH2O = Cd * a;
-    const double RT2 = k::R * T * T;
-    const double kf = kin[0] * exp(-kin[1] / k::R / T), dkf = kf * kin[1] / RT2;
-    const double ks = kin[2] * exp(-kin[3] / k::R / T), dks = ks * kin[3] / RT2;
-    const double kc = kin[4] * exp(-kin[5] / k::R / T), dkc = kc * kin[5] / RT2;
-    const double kh = kin[6] * exp(-kin[7] / k::R / T), dkh = kh * kin[7] / RT2;
+    const double iRT = iR * iT, iRT2 = iRT * iT;
+    const double kf = kin[0] * exp(-kin[1] * iRT), dkf = kf * kin[1] * iRT2;
+    const double ks = kin[2] * exp(-kin[3] * iRT), dks = ks * kin[3] * iRT2;
+    const double kc = kin[4] * exp(-kin[5] * iRT), dkc = kc * kin[5] * iRT2;
+    const double kh = kin[6] * exp(-kin[7] * iRT), dkh = kh * kin[7] * iRT2;
     const double A = 5075e3;
     const bool clamp = !(PH2 > 0.001);
     const double PH2c = clamp ? 0.001 : PH2;
     const double s = sqrt(PH2c);
-    const double q = kc * PCO2, q1 = 1 + q;
-    const double rf = A * kf * q * s / (q1 * q1);
-    const double drf_dq = A * kf * s * (1 - q) / (q1 * q1 * q1);
+    const double q = kc * PCO2, q1 = 1 + q, iq1 = 1.0 / q1, iq2 = iq1 * iq1;
+    const double rf = A * kf * q * s * iq2;
+    const double drf_dq = A * kf * s * (1 - q) * (iq2 * iq1);
     const double drf_dP = clamp ? 0.0 : rf * 0.5 / PH2c;
-    const double w = kh * PH2O, w1 = 1 + w;
-    const double rr = A * ks * w * (PCH4 * PCH4) / (w1 * w1);
-    const double drr_dw = A * ks * (PCH4 * PCH4) * (1 - w) / (w1 * w1 * w1);
-    const double drr_dP = A * ks * w * 2 * PCH4 / (w1 * w1);
+    const double w = kh * PH2O, w1 = 1 + w, iw1 = 1.0 / w1, iw2 = iw1 * iw1;
+    const double rr = A * ks * w * (PCH4 * PCH4) * iw2;
+    const double drr_dw = A * ks * (PCH4 * PCH4) * (1 - w) * (iw2 * iw1);
+    const double drr_dP = A * ks * w * 2 * PCH4 * iw2;
     g[0] = drf_dP * a;
     g[1] = drf_dq * kc * a;
     g[2] = -drr_dP * a;
     g[3] = -drr_dw * kh * a;
-    const double drf_dT = (A * q * s / (q1 * q1)) * dkf + drf_dq * (dkc * PCO2 + kc * Cb * da) + drf_dP * Ca * da;
-    const double drr_dT = (A * w * (PCH4 * PCH4) / (w1 * w1)) * dks + drr_dw * (dkh * PH2O + kh * Cd * da) + drr_dP * Cc * da;
+    const double drf_dT = (A * q * s * iq2) * dkf + drf_dq * (dkc * PCO2 + kc * Cb * da) + drf_dP * Ca * da;
+    const double drr_dT = (A * w * (PCH4 * PCH4) * iw2) * dks + drr_dw * (dkh * PH2O + kh * Cd * da) + drr_dP * Cc * da;
     g[4] = drf_dT - drr_dT;
     return rf - rr;
 }
@@ -143,69 +148,72 @@ SMC_HD void node_eval(int i, const double *wm, const double *w0, const double *w
         if (JAC) { Db[5 * 7 + 5] = 1.0; Lb[5 * 7 + 5] = -1.0; Db[6 * 7 + 6] = 1.0; Lb[6 * 7 + 6] = -1.0; }
         return;
     }
-    const double dz2 = dz * dz;
+    const double idz = 1.0 / dz, idz2 = idz * idz;
     const double Ti = w0[5], Tm = wm[5], Tp = wp[5], ui = w0[6], um = wm[6];
+    const double iTi = 1.0 / Ti, iTm = 1.0 / Tm, iTp = 1.0 / Tp;
     double g[5];
-    const double r = rate_and_grad(Ti, w0[0], w0[1], w0[2], w0[3], p + 10, g);
+    const double r = rate_and_grad(Ti, iTi, w0[0], w0[1], w0[2], w0[3], p + 10, g);
     const double sc[5] = {-4, -1, 1, 2, 0};
-    const double dif = vd * k::Dz / dz2;
+    const double dif = vd * k::Dz * idz2;
     SMC_UNROLL
     for (int f = 0; f < 5; ++f) {  // :105-109 / :115-119
         const double ci = w0[f], cm = wm[f], cp = wp[f];
         const double diff = (i == 1) ? (cp - ci) : (cp - 2 * ci + cm);
-        res[f] = -vd * yd0[f] - (ui * ci - um * cm) / dz + vd * k::Dz * diff / dz2 + (1 - vd) * sc[f] * r;
+        res[f] = -vd * yd0[f] - (ui * ci - um * cm) * idz + vd * k::Dz * diff * idz2 + (1 - vd) * sc[f] * r;
         if (JAC) {
             const double rs = (1 - vd) * sc[f];
             SMC_UNROLL
             for (int gg = 0; gg < 4; ++gg) Db[f * 7 + gg] = rs * g[gg];
-            Db[f * 7 + f] += -vd * cj - ui / dz - ((i == 1) ? dif : 2 * dif);
+            Db[f * 7 + f] += -vd * cj - ui * idz - ((i == 1) ? dif : 2 * dif);
             Db[f * 7 + 5] = rs * g[4];
-            Db[f * 7 + 6] = -ci / dz;
-            Lb[f * 7 + f] = um / dz + ((i == 1) ? 0.0 : dif);
-            Lb[f * 7 + 6] = cm / dz;
+            Db[f * 7 + 6] = -ci * idz;
+            Lb[f * 7 + f] = um * idz + ((i == 1) ? 0.0 : dif);
+            Lb[f * 7 + 6] = cm * idz;
             Ub[f * 7 + f] = dif;
         }
     }
     // gas density (:61-66) and its derivatives
     const double Ssum = w0[0] + w0[1] + w0[2] + w0[3] + w0[4];
     const double Nsum = w0[0] * 2 + w0[1] * 44 + w0[2] * 16 + w0[3] * 18 + w0[4] * 40;
-    const double pref = P0 / k::R / Ti;
-    const double rg = pref * Nsum / Ssum * 0.001;
+    const double pref = P0 * (1.0 / k::R) * iTi;
+    const double iS = 1.0 / Ssum;
+    const double rg = pref * Nsum * iS * 0.001;
     const double dT = yd0[5];
     const double kap = (i == 1) ? 1.0 : 0.1;  // :111 vs :126
     const double cap = vd * rg * k::Cpg + (1 - vd) * k::Rhos * k::Cps;
     const double conv = Ti * ui - Tm * um;
     // solver row 5 = energy balance (reference slot 6)
-    res[5] = -kap * cap * dT - rg * k::Cpg * conv / dz + k::Keff * (Tp - 2 * Ti + Tm) / dz2 + (1 - vd) * (-k::Hr) * r -
+    res[5] = -kap * cap * dT - rg * k::Cpg * conv * idz + k::Keff * (Tp - 2 * Ti + Tm) * idz2 + (1 - vd) * (-k::Hr) * r -
              2 * k::U / k::Dint * (Ti - T_jacket);
     // solver row 6 = total balance (reference slot 5)
-    const double tb = -ui * P0 * (1 / Ti - 1 / Tm) / dz - P0 / Ti * (ui - um) / dz +
-                      vd * k::Dz * P0 * (1 / Tp - 2 / Ti + 1 / Tm) / dz2 + (1 - vd) * k::R * (-2) * r;
-    res[6] = (i == 1) ? (P0 * vd * (1.0 / (Ti * Ti)) * dT + tb) : tb;
+    const double tb = -ui * P0 * (iTi - iTm) * idz - P0 * iTi * (ui - um) * idz +
+                      vd * k::Dz * P0 * (iTp - 2 * iTi + iTm) * idz2 + (1 - vd) * k::R * (-2) * r;
+    res[6] = (i == 1) ? (P0 * vd * (iTi * iTi) * dT + tb) : tb;
     if (JAC) {
         const double mw[5] = {2, 44, 16, 18, 40};
-        const double drg_dT = -rg / Ti;
+        const double drg_dT = -rg * iTi;
         const double he = (1 - vd) * (-k::Hr);
         SMC_UNROLL
         for (int gg = 0; gg < 5; ++gg) {
-            const double drg = pref * 0.001 * (mw[gg] * Ssum - Nsum) / (Ssum * Ssum);
-            Db[5 * 7 + gg] = -kap * vd * k::Cpg * drg * dT - k::Cpg * drg * conv / dz + ((gg < 4) ? he * g[gg] : 0.0);
+            const double drg = pref * 0.001 * (mw[gg] * Ssum - Nsum) * (iS * iS);
+            Db[5 * 7 + gg] = -kap * vd * k::Cpg * drg * dT - k::Cpg * drg * conv * idz + ((gg < 4) ? he * g[gg] : 0.0);
         }
-        Db[5 * 7 + 5] = -kap * (cap * cj + vd * k::Cpg * drg_dT * dT) - k::Cpg * (drg_dT * conv + rg * ui) / dz -
-                        2 * k::Keff / dz2 + he * g[4] - 2 * k::U / k::Dint;
-        Db[5 * 7 + 6] = -rg * k::Cpg * Ti / dz;
-        Lb[5 * 7 + 5] = rg * k::Cpg * um / dz + k::Keff / dz2;
-        Lb[5 * 7 + 6] = rg * k::Cpg * Tm / dz;
-        Ub[5 * 7 + 5] = k::Keff / dz2;
+        Db[5 * 7 + 5] = -kap * (cap * cj + vd * k::Cpg * drg_dT * dT) - k::Cpg * (drg_dT * conv + rg * ui) * idz -
+                        2 * k::Keff * idz2 + he * g[4] - 2 * k::U / k::Dint;
+        Db[5 * 7 + 6] = -rg * k::Cpg * Ti * idz;
+        Lb[5 * 7 + 5] = rg * k::Cpg * um * idz + k::Keff * idz2;
+        Lb[5 * 7 + 6] = rg * k::Cpg * Tm * idz;
+        Ub[5 * 7 + 5] = k::Keff * idz2;
         const double ht = (1 - vd) * k::R * (-2);
         SMC_UNROLL
         for (int gg = 0; gg < 4; ++gg) Db[6 * 7 + gg] = ht * g[gg];
-        Db[6 * 7 + 5] = -ui * P0 * (-1 / (Ti * Ti)) / dz + P0 / (Ti * Ti) * (ui - um) / dz + dif * P0 * (2 / (Ti * Ti)) + ht * g[4];
-        if (i == 1) Db[6 * 7 + 5] += P0 * vd * (-2.0 / (Ti * Ti * Ti) * dT + cj / (Ti * Ti));
-        Db[6 * 7 + 6] = -P0 * (1 / Ti - 1 / Tm) / dz - P0 / (Ti * dz);
-        Lb[6 * 7 + 5] = -ui * P0 * (1 / (Tm * Tm)) / dz + dif * P0 * (-1 / (Tm * Tm));
-        Lb[6 * 7 + 6] = P0 / (Ti * dz);
-        Ub[6 * 7 + 5] = dif * P0 * (-1 / (Tp * Tp));
+        const double iTi2 = iTi * iTi;
+        Db[6 * 7 + 5] = ui * P0 * iTi2 * idz + P0 * iTi2 * (ui - um) * idz + dif * P0 * (2 * iTi2) + ht * g[4];
+        if (i == 1) Db[6 * 7 + 5] += P0 * vd * (-2.0 * (iTi2 * iTi) * dT + cj * iTi2);
+        Db[6 * 7 + 6] = -P0 * (iTi - iTm) * idz - P0 * iTi * idz;
+        Lb[6 * 7 + 5] = -ui * P0 * (iTm * iTm) * idz - dif * P0 * (iTm * iTm);
+        Lb[6 * 7 + 6] = P0 * iTi * idz;
+        Ub[6 * 7 + 5] = -dif * P0 * (iTp * iTp);
     }
 }
 

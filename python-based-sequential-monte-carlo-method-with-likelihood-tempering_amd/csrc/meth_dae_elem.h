@@ -23,20 +23,47 @@
 // LDS per wave: differences array 8 x 7 x 51, L/U coefficients 51 x 24, staging 357 + 408 doubles = 38.8 KB, so four
 // waves (one per SIMD) still share a CU.  Time stepping, Newton control and error tests are those of meth_dae.h.
 // PARITY UNPINNED against the reference's IDA (see meth_dae.h); checked against v2, the CPU build and the CPU checker.
+//
+// Round 4: TWO-ENDED elimination.  K8 is bound by dependent chains at one wave per SIMD (vector ALUs busy 44 % of the cycles,
+// profiles/r04_k8_pmc_sq_summary.json): a scan step waits ~13 cycles for every dependent FP64 operation while the issue slots
+// stay empty, and neither a second wave per SIMD (204 VGPRs of factors, 38.8 KB of LDS per solve) nor the matrix cores (a chained
+// v_mfma_f64_4x4x4 costs 48 cycles) are a way out.  What a single wave CAN do is run two independent chains in one instruction
+// stream.  The block-tridiagonal system is therefore eliminated from BOTH ends at once ("twisted" / burn-at-both-ends
+// factorisation): nodes 0 .. 24 downwards as before (D'_i = D_i - L_i G_{i-1},  G_i = D'_i^{-1} U_i), nodes 50 .. 26 upwards
+// (D''_i = D_i - U_i H_{i+1},  H_i = D''_i^{-1} L_i), meeting in node 25 (D*_25 = D_25 - L_25 G_24 - U_25 H_26); the right-hand
+// side runs inwards on both chains (z_i = X_i (b_i - L_i z_{i-1}),  w_i = X_i (b_i - U_i w_{i+1})), the middle node is solved,
+// and the solution runs outwards on both (x_i = z_i - G_i x_{i+1},  x_i = w_i - H_i x_{i-1}).  Same flops, same storage (one
+// inverse and one coupling factor per node), half the chain length; node k and node 50 - k have the same parity, hence the same
+// lane layout, and are written side by side in one basic block so that the compiler interleaves the two dependency chains.
+// Without pivoting the two-ended elimination is as accurate as the one-way one on this matrix (180 iteration matrices over
+// prior-box parameters, states along solves and c = 1e-5 .. 10: worst relative error 3.8e-10 for both against a pivoted dense
+// solve; the check is described in DESIGN.md 4.5).  SMC_K8_TWISTED=0 builds the one-way scans of rounds 1-3 (A/B).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "meth_dae.h"
 #include "meth_dae_wave.h"
 
+#ifndef SMC_K8_TWISTED
+#define SMC_K8_TWISTED 1
+#endif
+
 namespace smc {
 namespace meth {
 
+constexpr int kMid = kNX / 2;    // node where the two elimination chains meet (25)
+static_assert(kNX == 2 * kMid + 1 && (kMid & 1) == 1, "the paired scans assume 51 nodes: pairs (k, 50 - k), k = 0 .. 24, and an odd middle node");
+
+// Row strides chosen against LDS bank conflicts where lane = node touches its own row (64 banks of 4 bytes): a stride of 24
+// doubles (48 banks) or 8 doubles (16 banks) puts every fourth lane on the same banks - 16-way conflicts on every write of the
+// coefficient rows and every read of the solution rows; 25 and 9 doubles (50 / 18 banks) leave 2-way conflicts.
+constexpr int kCfRow = 25, kZRow = 9;
 constexpr int kLdsD = 0;                         // D[k][f][node], k < 8
-constexpr int kLdsCf = kLdsD + 8 * 7 * kNX;      // per node 24: Ld[0..6],0 | Lx[0..6],0 | Ud[0..5],0,U65
-constexpr int kLdsB = kLdsCf + kNX * 24;         // b[node][7]  (also the staging row of the Jacobian transposition)
-constexpr int kLdsZ = kLdsB + kNX * 7;           // z / x [node][8]; slot 7 of a node takes the writes of the lanes that hold no result
-constexpr int kLdsDoubles = kLdsZ + kNX * 8;     // 4845 doubles = 38760 bytes
+constexpr int kLdsCf = kLdsD + 8 * 7 * kNX;      // per node kCfRow: Ld[0..6],0 | Lx[0..6],0 | Ud[0..5],0,U65 | pad
+constexpr int kLdsB = kLdsCf + kNX * kCfRow;         // b[node][7]  (also the staging row of the Jacobian transposition)
+constexpr int kLdsZ = kLdsB + kNX * 7;           // z / x [node][kZRow]; slot 7 of a node takes the writes of the lanes that hold no result
+constexpr int kLdsDoubles = kLdsZ + kNX * kZRow; // 4947 doubles = 39576 bytes: four waves (one per SIMD) still share a CU's 160 KB
+static_assert(kLdsDoubles * 8 * 4 <= 160 * 1024, "four solves per CU");
 
 struct DViewE {   // differences array, node-major within a row (only lanes < kNX may touch it)
     double *s;
@@ -88,6 +115,50 @@ __device__ __forceinline__ double allsum_over_mc(double v) {   // Q = node parit
     return allsum_across8(v);
 }
 
+// The same reduction for TWO independent values, level by level side by side: each DPP / permlane move of one chain fills the
+// wait states and the latency of the other's add.  The scheduling barriers keep the compiler from putting one butterfly after
+// the other again (its scheduler minimises register pressure, not latency, in a kernel at the register limit).
+#define SMC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void swap16_pair(double v, double &x, double &y) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = __hiloint2double((int)b[0], (int)a[0]);
+    y = __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ void swap32_pair(double v, double &x, double &y) {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = __hiloint2double((int)b[0], (int)a[0]);
+    y = __hiloint2double((int)b[1], (int)a[1]);
+}
+template <int Q>
+__device__ __forceinline__ void allsum_over_mc_pair(double &p, double &q) {
+    SMC_SCHED_FENCE();
+    if (Q == 0) {
+        double tp = dpp_mov<0xB1>(p), tq = dpp_mov<0xB1>(q);
+        p += tp; q += tq;
+        SMC_SCHED_FENCE();
+        tp = dpp_mov<0x4E>(p); tq = dpp_mov<0x4E>(q);
+        p += tp; q += tq;
+        SMC_SCHED_FENCE();
+        tp = dpp_mov<0x141>(p); tq = dpp_mov<0x141>(q);
+        p += tp; q += tq;
+    } else {
+        double tp = dpp_mov<0x128>(p), tq = dpp_mov<0x128>(q);
+        p += tp; q += tq;
+        SMC_SCHED_FENCE();
+        double px, py, qx, qy;
+        swap16_pair(p, px, py); swap16_pair(q, qx, qy);
+        p = px + py; q = qx + qy;
+        SMC_SCHED_FENCE();
+        swap32_pair(p, px, py); swap32_pair(q, qx, qy);
+        p = px + py; q = qx + qy;
+    }
+    SMC_SCHED_FENCE();
+}
+
 struct ElemLane {   // lane = 8 r + c
     int r, c, lane;
     __device__ __forceinline__ explicit ElemLane(int l) : r(l >> 3), c(l & 7), lane(l) {}
@@ -109,12 +180,19 @@ __device__ __forceinline__ double recip1(double a) {
     return fma(x, fma(-a, x, 1.0), x);
 }
 
+// ... with ONE Newton step (2^-48): what the two-ended elimination's Gauss-Jordan uses - the explicit inverse of a modified
+// Newton iteration's matrix steers convergence only, and two instructions per pivot and chain are 4 % of a factorisation
+__device__ __forceinline__ double recip1_short(double a) {
+    const double x = __builtin_amdgcn_rcp(a);
+    return fma(x, fma(-a, x, 1.0), x);
+}
+
 // one node of the block elimination; Q = I & 1
 template <int I>
 __device__ __forceinline__ bool elem_factor_node(const ElemLane &L, const double *cf, double (&X)[kNX], double (&G)[kNX]) {
     constexpr int Q = I & 1;
     const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
-    const double *cfi = cf + I * 24;
+    const double *cfi = cf + I * kCfRow;
     double a = X[I];
     if (I > 0) {
         constexpr int IP = (I > 0) ? I - 1 : 0;
@@ -165,6 +243,222 @@ struct ElemFactorLoop<-1> {
     static __device__ __forceinline__ bool run(const ElemLane &, const double *, double (&)[kNX], double (&)[kNX]) { return true; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// two-ended elimination: node pair (K, 50 - K) side by side; Q = K & 1 is the parity of both
+// ---------------------------------------------------------------------------------------------
+// Layout reminders (Q = node parity): lane (r, c) holds element [mr][mc] with (mr, mc) = Q ? (c, r) : (r, c); the factor of a
+// NEIGHBOUR node (parity 1 - Q) element [a][b] sits in lane (1-Q ? (b, a) : (a, b)).  L_i = diag(ld) + column 6 (rows 0..5: lx) +
+// L[6][5] (lx[6]);  U_i = diag(ud[0..5]) + U[6][5] (u65)  (cf row of the node: [0..6] ld, [8..14] lx, [16..21] ud, [23] u65).
+// branch-free (bitwise &): a scalar branch per pivot would cut the basic block in which the two chains are interleaved
+__device__ __forceinline__ int gj_pivot_ok(double v) { return (int)(fabs(v) > 1e-300) & (int)(fabs(v) < 1e300); }
+
+template <int K>
+__device__ __forceinline__ bool elem_factor_pair(const ElemLane &L, const double *cf, double (&X)[kNX], double (&G)[kNX]) {
+    constexpr int T = K, B = kNX - 1 - K, Q = K & 1;
+    const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
+    const double *cT = cf + T * kCfRow, *cB = cf + B * kCfRow;
+    double aT = X[T], aB = X[B];
+    if (K > 0) {
+        constexpr int TP = (K > 0) ? T - 1 : 0, BP = (K > 0) ? B + 1 : kNX - 1;
+        const int srcT = L.c * 8 + L.r;                              // neighbour's [mr][mc]
+        {   // top:  D' = D - L_T G_{T-1}:  (L G)[mr][mc] = ld[mr] G[mr][mc] + lx[mr] G[mr < 6 ? 6 : 5][mc]
+            const int kap = mr < 6 ? 6 : 5;
+            const int srcK = Q ? (kap * 8 + L.r) : (L.c * 8 + kap);
+            const double gT = __shfl(G[TP], srcT), gK = __shfl(G[TP], srcK);
+            aT = fma(-cT[8 + min6(mr)], gK, fma(-cT[min6(mr)], gT, aT));
+        }
+        {   // bottom:  D'' = D - U_B H_{B+1}:  (U H)[mr][mc] = ud[mr] H[mr][mc] (mr < 6),  u65 H[5][mc] (mr == 6)
+            const int src5 = Q ? (5 * 8 + L.r) : (L.c * 8 + 5);
+            const double hT = __shfl(G[BP], srcT), h5 = __shfl(G[BP], src5);
+            const double cu = cB[(mr == 6) ? 23 : 16 + min6(mr)];         // ONE load (padding row 7: cB[22] == 0)
+            aB = fma(-cu, (mr == 6) ? h5 : hT, aB);
+        }
+    }
+    // two Gauss-Jordan inversions, pivot by pivot side by side (see elem_factor_node for the single form)
+    int ok = 1;
+    const double rowsign = Q ? -1.0 : 1.0;
+    double akT = lane_bcast(aT, 0), akB = lane_bcast(aB, 0);
+    SMC_UNROLL
+    for (int kk = 0; kk < 7; ++kk) {
+        ok &= gj_pivot_ok(akT) & gj_pivot_ok(akB);
+        const double pT = recip1_short(akT), pB = recip1_short(akB);
+        const int su = (L.lane & ~7) | kk, sv = kk * 8 + L.c;
+        const double uT = __shfl(aT, su), uB = __shfl(aB, su);
+        const double vT = __shfl(aT, sv), vB = __shfl(aB, sv);
+        const double genT = fma(-(uT * vT), pT, aT), genB = fma(-(uB * vB), pB, aB);
+        akT = lane_bcast(genT, kk < 6 ? 9 * kk + 9 : 0);
+        akB = lane_bcast(genB, kk < 6 ? 9 * kk + 9 : 0);
+        const double apT = aT * pT * rowsign, apB = aB * pB * rowsign;
+        const bool rk = L.r == kk, ck = L.c == kk;
+        aT = rk ? (ck ? pT : apT) : (ck ? -apT : genT);
+        aB = rk ? (ck ? pB : apB) : (ck ? -apB : genB);
+    }
+    X[T] = aT;
+    X[B] = aB;
+    const int src6 = Q ? (48 + L.c) : ((L.lane & ~7) | 6);          // holder of X[mr][6]
+    {   // G_T = X_T U_T:  [mr][mc] = X[mr][mc] ud[mc] + (mc == 5) X[mr][6] u65
+        const double tU = __shfl(aT, src6), ud = cT[16 + min6(mc)], u65 = cT[23];     // loads outside the selects: no exec-mask branches
+        const double extra = tU * u65;
+        G[T] = fma(aT, ud, (mc == 5) ? extra : 0.0);
+    }
+    {   // H_B = X_B L_B:  [mr][mc] = X[mr][mc] ld[mc] + (mc == 6) sum_{k<6} X[mr][k] lx[k] + (mc == 5) X[mr][6] lx[6]
+        const double x6 = __shfl(aB, src6), lxv = cB[8 + min6(mc)], ldv = cB[min6(mc)], lx6 = cB[8 + 6];
+        const double pr = aB * lxv, e5 = x6 * lx6;
+        const double S = allsum_over_mc<Q>((mc < 6) ? pr : 0.0);
+        G[B] = fma(aB, ldv, (mc == 6) ? S : ((mc == 5) ? e5 : 0.0));
+    }
+    return ok != 0;
+}
+template <int K>
+struct ElemFactorPairLoop {
+    static __device__ __forceinline__ bool run(const ElemLane &L, const double *cf, double (&X)[kNX], double (&G)[kNX]) {
+        const bool before = ElemFactorPairLoop<K - 1>::run(L, cf, X, G);
+        return elem_factor_pair<K>(L, cf, X, G) && before;
+    }
+};
+template <>
+struct ElemFactorPairLoop<-1> {
+    static __device__ __forceinline__ bool run(const ElemLane &, const double *, double (&)[kNX], double (&)[kNX]) { return true; }
+};
+// the node where the chains meet:  D* = D - L G_{m-1} - U H_{m+1},  X_m = D*^{-1}  (no coupling factor)
+__device__ __forceinline__ bool elem_factor_middle(const ElemLane &L, const double *cf, double (&X)[kNX], const double (&G)[kNX]) {
+    constexpr int I = kMid, Q = I & 1;
+    const int mr = L.template mr<Q>();
+    const double *cfi = cf + I * kCfRow;
+    double a = X[I];
+    {
+        const int srcT = L.c * 8 + L.r;
+        const int kap = mr < 6 ? 6 : 5;
+        const int srcK = Q ? (kap * 8 + L.r) : (L.c * 8 + kap), src5 = Q ? (5 * 8 + L.r) : (L.c * 8 + 5);
+        const double gT = __shfl(G[I - 1], srcT), gK = __shfl(G[I - 1], srcK);
+        const double hT = __shfl(G[I + 1], srcT), h5 = __shfl(G[I + 1], src5);
+        a = fma(-cfi[8 + min6(mr)], gK, fma(-cfi[min6(mr)], gT, a));
+        const double cu = cfi[(mr == 6) ? 23 : 16 + min6(mr)];
+        a = fma(-cu, (mr == 6) ? h5 : hT, a);
+    }
+    int ok = 1;
+    const double rowsign = Q ? -1.0 : 1.0;
+    double akk = lane_bcast(a, 0);
+    SMC_UNROLL
+    for (int kk = 0; kk < 7; ++kk) {
+        ok &= gj_pivot_ok(akk);
+        const double p = recip1(akk);
+        const double u = __shfl(a, (L.lane & ~7) | kk), v = __shfl(a, kk * 8 + L.c);
+        const double gen = fma(-(u * v), p, a);
+        akk = lane_bcast(gen, kk < 6 ? 9 * kk + 9 : 0);
+        const double ap = a * p * rowsign;
+        const bool rk = L.r == kk, ck = L.c == kk;
+        a = rk ? (ck ? p : ap) : (ck ? -ap : gen);
+    }
+    X[I] = a;
+    return ok != 0;
+}
+
+// Right-hand side inwards on both chains.  zprev / wprev: results of the previous pair on this lane's input index mc; the
+// operands of the NEXT pair are loaded before this pair's results are stored (the compiler must assume the stores alias them).
+//   top:     t = b - ld z_prev - lxa z_prev[6] - lxb z_prev[5]      lxa = mc < 6 ? L[mc][6] : 0,  lxb = mc >= 6 ? L[6][5] : 0
+//   bottom:  t = b - cua w_prev - cub w_prev[5]                      cua = mc < 6 ? U[mc][mc] : 0, cub = mc >= 6 ? U[6][5] : 0
+// The masks live in the per-lane ADDRESSES of the coefficient loads (a zero slot of the node's cf row where the coefficient
+// does not apply: FwdOffsets), so the broadcasts stay scalar operands of the FMAs - no v_mov from the SGPRs, no selects.
+struct FwdOffsets {     // per lane and parity: offsets into a node's cf row of 24 doubles ([7], [15], [22] hold zeros)
+    int ld, lxa, lxb, cua, cub, b;
+};
+template <int Q>
+__device__ __forceinline__ FwdOffsets fwd_offsets(const ElemLane &L) {
+    const int mc = L.template mc<Q>(), m6 = min6(mc);
+    FwdOffsets o;
+    o.ld = m6;
+    o.lxa = (mc < 6) ? 8 + mc : 7;
+    o.lxb = (mc < 6) ? 7 : 8 + 6;
+    o.cua = 16 + m6;                  // [22] == 0 for mc >= 6
+    o.cub = (mc < 6) ? 22 : 23;
+    o.b = m6;
+    return o;
+}
+struct FwdOperands {    // of one pair: loaded one pair ahead
+    double bT, ldT, lxaT, lxbT, bB, cuaB, cubB;
+};
+template <int K>
+struct ElemForwardPair {
+    static __device__ __forceinline__ void run(const ElemLane &L, const double *cf, const double *b, double *z, const double (&X)[kNX],
+                                               const FwdOffsets &o0, const FwdOffsets &o1, double zprev, double wprev,
+                                               const FwdOperands &op, double &zlast, double &wlast) {
+        constexpr int T = K, B = kNX - 1 - K, Q = K & 1, TN = T + 1, BN = B - 1;
+        const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
+        const FwdOffsets &on = Q ? o0 : o1;                  // offsets of the next pair's parity
+        FwdOperands nx;
+        nx.bT = b[TN * 7 + on.b];
+        nx.ldT = cf[TN * kCfRow + on.ld];
+        nx.lxaT = cf[TN * kCfRow + on.lxa];
+        nx.lxbT = cf[TN * kCfRow + on.lxb];
+        nx.bB = b[BN * 7 + on.b];
+        nx.cuaB = cf[BN * kCfRow + on.cua];
+        nx.cubB = cf[BN * kCfRow + on.cub];
+        double tT = op.bT, tB = op.bB;
+        if (K > 0) {
+            const double z6 = lane_bcast(zprev, Q ? 48 : 6), z5 = lane_bcast(zprev, Q ? 40 : 5);
+            const double w5 = lane_bcast(wprev, Q ? 40 : 5);
+            tT = fma(-op.lxbT, z5, fma(-op.lxaT, z6, fma(-op.ldT, zprev, tT)));
+            tB = fma(-op.cubB, w5, fma(-op.cuaB, wprev, tB));
+        }
+        double zi = X[T] * tT, wi = X[B] * tB;
+        allsum_over_mc_pair<Q>(zi, wi);
+        const int slot = (mc == 0 && mr < 7) ? mr : 7;       // one unconditional store each: no exec-mask round trip per step
+        z[T * kZRow + slot] = zi;
+        z[B * kZRow + slot] = wi;
+        if constexpr (K + 1 < kMid) {
+            ElemForwardPair<K + 1>::run(L, cf, b, z, X, o0, o1, zi, wi, nx, zlast, wlast);
+        } else {
+            zlast = zi;
+            wlast = wi;
+        }
+    }
+};
+// Solution outwards on both chains, K = 24 .. 0:  x_T = z_T - G_T x_{T+1},  x_B = w_B - H_B x_{B-1}  (H is kept in G[B]).
+// xT / xB: the inner neighbours' solutions on this lane's input index mc; zT / wB: this pair's z / w on the lane's row index mr.
+template <int K>
+struct ElemBackwardPair {
+    static __device__ __forceinline__ void run(const ElemLane &L, double *z, const double (&G)[kNX], double xT, double zT, double xB,
+                                               double wB) {
+        constexpr int T = K, B = kNX - 1 - K, Q = K & 1, QN = 1 - Q, KN = (K > 0) ? K - 1 : 0;
+        const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
+        const int mrn = min6(L.template mr<QN>());
+        const double zTn = z[KN * kZRow + mrn], wBn = z[(kNX - 1 - KN) * kZRow + mrn];
+        double st = G[T] * xT, sb = G[B] * xB;
+        allsum_over_mc_pair<Q>(st, sb);
+        const double xt = zT - st, xb = wB - sb;
+        const int slot = (mc == 0 && mr < 7) ? mr : 7;
+        z[T * kZRow + slot] = xt;
+        z[B * kZRow + slot] = xb;
+        if constexpr (K > 0) ElemBackwardPair<KN>::run(L, z, G, xt, zTn, xb, wBn);
+    }
+};
+// one linear solve with the two-ended factors: b (LDS, node-major) -> x in z (LDS, [node][8])
+__device__ __forceinline__ void elem_solve_twisted(const ElemLane &L, const double *cf, const double *b, double *z,
+                                                   const double (&X)[kNX], const double (&G)[kNX]) {
+    const FwdOffsets o0 = fwd_offsets<0>(L), o1 = fwd_offsets<1>(L);
+    double zl, wl;
+    {
+        FwdOperands op{};
+        op.bT = b[o0.b];
+        op.bB = b[(kNX - 1) * 7 + o0.b];
+        ElemForwardPair<0>::run(L, cf, b, z, X, o0, o1, 0.0, 0.0, op, zl, wl);
+    }
+    constexpr int I = kMid, Q = I & 1;
+    static_assert(Q == 1, "the middle node's offsets are o1");
+    const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
+    const double *cfi = cf + I * kCfRow;
+    const double z6 = lane_bcast(zl, Q ? 48 : 6), z5 = lane_bcast(zl, Q ? 40 : 5), w5 = lane_bcast(wl, Q ? 40 : 5);
+    double t = b[I * 7 + o1.b];
+    t = fma(-cfi[o1.lxb], z5, fma(-cfi[o1.lxa], z6, fma(-cfi[o1.ld], zl, t)));
+    t = fma(-cfi[o1.cub], w5, fma(-cfi[o1.cua], wl, t));
+    const int mrn = min6(L.template mr<1 - Q>());
+    const double zT = z[(I - 1) * kZRow + mrn], wB = z[(I + 1) * kZRow + mrn];      // loaded before x_m is stored
+    const double xm = allsum_over_mc<Q>(X[I] * t);
+    z[I * kZRow + ((mc == 0 && mr < 7) ? mr : 7)] = xm;
+    ElemBackwardPair<kMid - 1>::run(L, z, G, xm, zT, xm, wB);
+}
+
 // iteration matrix at the predictor (parallel over nodes), transposition into the element layout, block elimination
 __device__ __forceinline__ bool elem_build_and_factor(int lane, double *lds, const double *yp, const double *psi,
                                                       const double *p, double c, double (&X)[kNX], double (&G)[kNX], DaeStats &st) {
@@ -184,7 +478,7 @@ __device__ __forceinline__ bool elem_build_and_factor(int lane, double *lds, con
         SMC_UNROLL
         for (int i = 0; i < kNX; ++i) X[i] = 0.0;
         if (node) {
-            double *o = cf + lane * 24;
+            double *o = cf + lane * kCfRow;
             SMC_UNROLL
             for (int r = 0; r < 7; ++r) {
                 o[r] = Lb[r * 7 + r];
@@ -211,7 +505,12 @@ __device__ __forceinline__ bool elem_build_and_factor(int lane, double *lds, con
         }
     }
     SMC_PROF_ADD(st, 7);   // Jacobian blocks + transposition
+#if SMC_K8_TWISTED
+    bool ok = ElemFactorPairLoop<kMid - 1>::run(L, cf, X, G);
+    ok = elem_factor_middle(L, cf, X, G) && ok;
+#else
     const bool ok = ElemFactorLoop<kNX - 1>::run(L, cf, X, G);
+#endif
     SMC_PROF_ADD(st, 0);   // block elimination
     return __all(ok);
 }
@@ -226,7 +525,7 @@ struct ElemForward {
         constexpr int Q = I & 1, QN = 1 - Q, IN = (I + 1 < kNX) ? I + 1 : I;
         const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
         const int mcn = min6(L.template mc<QN>());
-        const double bN = b[IN * 7 + mcn], ldN = cf[IN * 24 + mcn], lxN = cf[IN * 24 + 8 + mcn];
+        const double bN = b[IN * 7 + mcn], ldN = cf[IN * kCfRow + mcn], lxN = cf[IN * kCfRow + 8 + mcn];
         double t = bI;
         if (I > 0) {
             const double z6 = lane_bcast(zprev, Q ? 48 : 6), z5 = lane_bcast(zprev, Q ? 40 : 5);
@@ -234,7 +533,7 @@ struct ElemForward {
             t = fma(-lxI, zx, fma(-ldI, zprev, t));
         }
         const double zi = allsum_over_mc<Q>(X[I] * t);
-        z[I * 8 + ((mc == 0 && mr < 7) ? mr : 7)] = zi;   // one unconditional store: no exec-mask round trip per step
+        z[I * kZRow + ((mc == 0 && mr < 7) ? mr : 7)] = zi;   // one unconditional store: no exec-mask round trip per step
         if constexpr (I + 1 < kNX) return ElemForward<IN>::run(L, cf, b, z, X, zi, bN, ldN, lxN);
         else return zi;
     }
@@ -246,9 +545,9 @@ struct ElemBackward {
     static __device__ __forceinline__ void run(const ElemLane &L, double *z, const double (&G)[kNX], double xnext, double zI) {
         constexpr int Q = I & 1, QN = 1 - Q, IN = (I > 0) ? I - 1 : 0;
         const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
-        const double zN = z[IN * 8 + min6(L.template mr<QN>())];
+        const double zN = z[IN * kZRow + min6(L.template mr<QN>())];
         const double xi = zI - allsum_over_mc<Q>(G[I] * xnext);
-        z[I * 8 + ((mc == 0 && mr < 7) ? mr : 7)] = xi;
+        z[I * kZRow + ((mc == 0 && mr < 7) ? mr : 7)] = xi;
         if constexpr (I > 0) ElemBackward<IN>::run(L, z, G, xi, zN);
     }
 };
@@ -282,18 +581,25 @@ __device__ __forceinline__ double elem_newton_iteration(int lane, double *lds, d
     if (!__all(finite)) return -1.0;
     wave_lds_sync();
     SMC_PROF_ADD(st, 1);
+#if SMC_K8_TWISTED
+    elem_solve_twisted(L, cf, b, z, X, G);
+    SMC_PROF_ADD(st, 2);   // both scans (slot 3 stays empty)
+#else
     const double zlast = ElemForward<0>::run(L, cf, b, z, X, 0.0, b[min6(L.c)], 0.0, 0.0);
     SMC_PROF_ADD(st, 2);
-    ElemBackward<kNX - 2>::run(L, z, G, zlast, z[(kNX - 2) * 8 + min6(L.template mr<(kNX - 2) & 1>())]);
+    ElemBackward<kNX - 2>::run(L, z, G, zlast, z[(kNX - 2) * kZRow + min6(L.template mr<(kNX - 2) & 1>())]);
+#endif
     wave_lds_sync();
     SMC_PROF_ADD(st, 3);
     double sumsq = 0.0;
     if (node)
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) {
-            const double dx = z[lane * 8 + f];
+            const double dx = z[lane * kZRow + f];
             const double sc = atol + rtol * fabs(yp[f]);
-            const double q = dx / sc;
+            // weights of a convergence norm: the reciprocal with two Newton steps (~1 ulp) instead of the IEEE division's
+            // scaling / fix-up sequence (13 instructions per component and iteration; sc is within [atol, atol + rtol |y|])
+            const double q = dx * recip1(sc);
             sumsq += q * q;
             y[f] += dx;
             dd[f] += dx;
@@ -441,8 +747,9 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
                 ++st.newton_iters;
                 if (dy_norm < 0) break;
                 const double rate = (dy_norm_old >= 0) ? dy_norm / dy_norm_old : -1.0;
-                if (rate >= 0 && (rate >= 1 || ipow_small(rate, kNewtonMaxIter - kk) / (1 - rate) * dy_norm > newton_tol)) break;
-                if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = true; break; }
+                const double scaled = dy_norm / (1 - rate);      // dy_norm / (1 - rate): shared by both tests (one division, not two)
+                if (rate >= 0 && (rate >= 1 || ipow_small(rate, kNewtonMaxIter - kk) * scaled > newton_tol)) break;
+                if (dy_norm == 0 || (rate >= 0 && rate * scaled < newton_tol)) { converged = true; break; }
                 dy_norm_old = dy_norm;
             }
         }
@@ -464,8 +771,8 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
         if (node)
             SMC_UNROLL
             for (int f = 0; f < 6; ++f) {
-                const double sc = atol + rtol * fabs(y[f]);
-                const double e = bdf_error_const(order) * dd[f] / sc;
+                const double isc = recip1(atol + rtol * fabs(y[f]));      // weights of an error norm: see elem_newton_iteration
+                const double e = bdf_error_const(order) * dd[f] * isc;
                 se += e * e;
             }
         const double error_norm = sqrt(allsum_wave(se) / (6 * kNX));
@@ -505,9 +812,9 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
             if (select)
                 SMC_UNROLL
                 for (int f = 0; f < 6; ++f) {
-                    const double sc = atol + rtol * fabs(y[f]);
-                    if (order > 1) { const double e = bdf_error_const(order - 1) * d_order[f] / sc; sm += e * e; }
-                    if (order < kMaxOrder) { const double e = bdf_error_const(order + 1) * dnew2[f] / sc; sp += e * e; }
+                    const double isc = recip1(atol + rtol * fabs(y[f]));
+                    if (order > 1) { const double e = bdf_error_const(order - 1) * d_order[f] * isc; sm += e * e; }
+                    if (order < kMaxOrder) { const double e = bdf_error_const(order + 1) * dnew2[f] * isc; sp += e * e; }
                 }
         }
         SMC_PROF_ADD(st, 10);  // D update + order-selection norms

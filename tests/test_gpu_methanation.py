@@ -481,7 +481,7 @@ def test_sharded_methanation_run_equals_single_rank(pkg, M, cond_guess, world):
     generic_accept_kernel / meth_certainly_rejected (global_offset = rank * n_local), and the per-rank misfit order of the
     experiments (every rank orders by its own block's statistics - any order must give the same results).
     Device-RNG mode is keyed by the global index, so the sharded run must reproduce the one-rank run: tempering schedule,
-    Metropolis lengths, accept counts and offspring counts exactly; particles and evidence to 1e-9, likelihoods to 1e-6 (the
+    Metropolis lengths, accept counts and offspring counts exactly; particles to 1e-9, likelihoods to 1e-6, evidence to 1e-7 (the
     cross-rank moment sums round differently from one block's tree, so proposals may differ in the last bits)."""
     cond, guess = cond_guess
     np.random.seed(20250205)
@@ -497,7 +497,7 @@ def test_sharded_methanation_run_equals_single_rank(pkg, M, cond_guess, world):
         assert [r["last_j"] for r in o["records"]] == [r["last_j"] for r in ref["records"]]
         assert [r["n_accept"] for r in o["records"]] == [r["n_accept"] for r in ref["records"]]
         assert [r["n_offspring"] for r in o["records"]] == [r["n_offspring"] for r in ref["records"]]
-        assert abs(o["logZ"] - ref["logZ"]) <= 1e-9 * abs(ref["logZ"])
+        assert abs(o["logZ"] - ref["logZ"]) <= 1e-7 * abs(ref["logZ"])          # a sum over likelihoods that agree to ~1e-7 (below)
     p = np.concatenate([o["p_pred"] for o in outs])
     lk = np.concatenate([o["lk"] for o in outs])
     assert p.shape == ref["p_pred"].shape
