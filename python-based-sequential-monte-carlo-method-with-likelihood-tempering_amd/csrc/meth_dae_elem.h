@@ -274,13 +274,14 @@ __device__ __forceinline__ bool elem_factor_pair(const ElemLane &L, const double
             aB = fma(-cu, (mr == 6) ? h5 : hT, aB);
         }
     }
-    // two Gauss-Jordan inversions, pivot by pivot side by side (see elem_factor_node for the single form)
-    int ok = 1;
+    // two Gauss-Jordan inversions, pivot by pivot side by side (see elem_factor_node for the single form).  No test per pivot
+    // (two compares and the scalar bookkeeping per pivot and chain were a fifth of the loop): a vanishing pivot shows in the
+    // inverse - its reciprocal sits on the diagonal, and 0 or a non-finite pivot turns the block into inf / NaN - and is caught
+    // by one magnitude test per element at the end.
     const double rowsign = Q ? -1.0 : 1.0;
     double akT = lane_bcast(aT, 0), akB = lane_bcast(aB, 0);
     SMC_UNROLL
     for (int kk = 0; kk < 7; ++kk) {
-        ok &= gj_pivot_ok(akT) & gj_pivot_ok(akB);
         const double pT = recip1_short(akT), pB = recip1_short(akB);
         const int su = (L.lane & ~7) | kk, sv = kk * 8 + L.c;
         const double uT = __shfl(aT, su), uB = __shfl(aB, su);
@@ -295,6 +296,7 @@ __device__ __forceinline__ bool elem_factor_pair(const ElemLane &L, const double
     }
     X[T] = aT;
     X[B] = aB;
+    const int ok = (int)(fabs(aT) < 1e300) & (int)(fabs(aB) < 1e300);      // false for NaN
     const int src6 = Q ? (48 + L.c) : ((L.lane & ~7) | 6);          // holder of X[mr][6]
     {   // G_T = X_T U_T:  [mr][mc] = X[mr][mc] ud[mc] + (mc == 5) X[mr][6] u65
         const double tU = __shfl(aT, src6), ud = cT[16 + min6(mc)], u65 = cT[23];     // loads outside the selects: no exec-mask branches
