@@ -1,0 +1,152 @@
+"""K8's linear algebra on the CPU (no GPU): the TWO-ENDED block elimination of round 4 (nodes 0..24 downwards, 50..26 upwards,
+meeting in node 25; csrc/meth_dae_elem.h) restated in NumPy on the product's own iteration matrix - csrc/meth_dae.h compiled with
+g++ (tests/hostcheck/meth_dae_hostcheck.cpp) - against a pivoted dense solve and against the one-way elimination of rounds 1-3.
+Both run WITHOUT pivoting (rows 5 / 6 of a node are swapped by node_eval so that none is needed); the kernel keeps explicit
+inverses because the matrix of a modified Newton iteration only steers convergence.  Also pins the reciprocal-sharing rewrite of
+the residual (round 4) to the product's own residual entry point and the structure of the off-diagonal blocks the scans rely on."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "hostcheck", "meth_dae_hostcheck.cpp")
+NX, NS, MID = 51, 357, 25
+dp = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="module")
+def hc(tmp_path_factory):
+    if not shutil.which("g++"):
+        pytest.skip("needs g++")
+    so = str(tmp_path_factory.mktemp("hc") / "libhc.so")
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-o", so, SRC], check=True)
+    L = ctypes.CDLL(so)
+    L.hc_itermatrix.argtypes = [dp, dp, dp, ctypes.c_double, dp]
+    L.hc_residual.argtypes = [dp, dp, dp, dp]
+    return L
+
+
+@pytest.fixture(scope="module")
+def M():
+    import __graft_entry__ as g
+    g.load_oracle()
+    from oracle import methanation
+    return methanation
+
+
+def _blocks(A):
+    D = [A[7 * i:7 * i + 7, 7 * i:7 * i + 7].copy() for i in range(NX)]
+    Lb = [None] + [A[7 * i:7 * i + 7, 7 * (i - 1):7 * i].copy() for i in range(1, NX)]
+    Ub = [A[7 * i:7 * i + 7, 7 * (i + 1):7 * (i + 2)].copy() for i in range(NX - 1)] + [None]
+    return Lb, D, Ub
+
+
+def _inv_nopivot(Mx):
+    a = Mx.copy()
+    for k in range(7):                       # the kernel's Gauss-Jordan: pivot k, no row exchange
+        p = 1.0 / a[k, k]
+        u, v = a[:, k].copy(), a[k, :].copy()
+        a = a - np.outer(u, v) * p
+        a[k, :] = v * p
+        a[:, k] = -u * p
+        a[k, k] = p
+    return a
+
+
+def _solve_one_way(Lb, D, Ub, b):
+    X, G = [None] * NX, [None] * NX
+    for i in range(NX):
+        X[i] = _inv_nopivot(D[i] - (Lb[i] @ G[i - 1] if i else 0))
+        if i < NX - 1:
+            G[i] = X[i] @ Ub[i]
+    z = [None] * NX
+    for i in range(NX):
+        z[i] = X[i] @ (b[7 * i:7 * i + 7] - (Lb[i] @ z[i - 1] if i else 0))
+    x = [None] * NX
+    x[-1] = z[-1]
+    for i in range(NX - 2, -1, -1):
+        x[i] = z[i] - G[i] @ x[i + 1]
+    return np.concatenate(x)
+
+
+def _solve_two_ended(Lb, D, Ub, b, m=MID):
+    X, G, H = [None] * NX, [None] * NX, [None] * NX
+    for i in range(m):                                                  # top chain
+        X[i] = _inv_nopivot(D[i] - (Lb[i] @ G[i - 1] if i else 0))
+        G[i] = X[i] @ Ub[i]
+    for i in range(NX - 1, m, -1):                                      # bottom chain
+        X[i] = _inv_nopivot(D[i] - (Ub[i] @ H[i + 1] if i < NX - 1 else 0))
+        H[i] = X[i] @ Lb[i]
+    X[m] = _inv_nopivot(D[m] - Lb[m] @ G[m - 1] - Ub[m] @ H[m + 1])      # where they meet
+    z = [None] * NX
+    for i in range(m):
+        z[i] = X[i] @ (b[7 * i:7 * i + 7] - (Lb[i] @ z[i - 1] if i else 0))
+    for i in range(NX - 1, m, -1):
+        z[i] = X[i] @ (b[7 * i:7 * i + 7] - (Ub[i] @ z[i + 1] if i < NX - 1 else 0))
+    x = [None] * NX
+    x[m] = X[m] @ (b[7 * m:7 * m + 7] - Lb[m] @ z[m - 1] - Ub[m] @ z[m + 1])
+    for i in range(m - 1, -1, -1):
+        x[i] = z[i] - G[i] @ x[i + 1]
+    for i in range(m + 1, NX):
+        x[i] = z[i] - H[i] @ x[i - 1]
+    return np.concatenate(x)
+
+
+def _matrix(hc, y, yd, p, cj):
+    A = np.zeros((NS, NS))
+    yc, ydc, pc = (np.ascontiguousarray(v, dtype=np.float64) for v in (y, yd, p))
+    hc.hc_itermatrix(yc.ctypes.data_as(dp), ydc.ctypes.data_as(dp), pc.ctypes.data_as(dp), cj, A.ctypes.data_as(dp))
+    return A
+
+
+def test_two_ended_elimination_is_as_accurate_as_the_one_way_one(hc, M):
+    """Iteration matrices of the product for prior-box parameters, states along real solves (start profile, final state, half way)
+    and c = h / alpha over six decades: both no-pivot eliminations against numpy.linalg.solve on random right-hand sides."""
+    cond = M.load_conditions(os.path.join(ROOT, "tests", "golden", "methanation_information.csv"))
+    guess = M.initial_guess(cond)
+    lo, hi, pos = M.prior_box()
+    rs = np.random.RandomState(1)
+    worst = {"one": 0.0, "two": 0.0}
+    cases = 0
+    for _ in range(6):
+        e = int(rs.randint(0, 30))
+        pr = M.BASEPARAMS.copy()
+        pr[:4] = (lo[pos] + (hi[pos] - lo[pos]) * rs.uniform(0.05, 0.95, 5))[:4]
+        p = M.p0_tuple(cond, e, pr)
+        yfin, rc, _ = M.dae_solve(guess[e], p)
+        for y in (guess[e], yfin, 0.5 * (guess[e] + yfin)):
+            for c in (1e-5, 1e-3, 1e-1, 10.0):
+                A = _matrix(hc, y, rs.standard_normal(NS) * 1e-3 * np.abs(y), p, 1.0 / c)
+                Lb, D, Ub = _blocks(A)
+                b = rs.standard_normal(NS) * np.abs(A).sum(axis=1)
+                ref = np.linalg.solve(A, b)
+                for k, f in (("one", _solve_one_way), ("two", _solve_two_ended)):
+                    worst[k] = max(worst[k], np.max(np.abs(f(Lb, D, Ub, b) - ref)) / np.max(np.abs(ref)))
+                cases += 1
+    print(f"{cases} matrices: worst relative error one-way {worst['one']:.2e}, two-ended {worst['two']:.2e}")
+    assert worst["two"] < 1e-8 and worst["two"] < 3 * worst["one"] + 1e-12
+
+
+def test_off_diagonal_blocks_have_the_structure_the_scans_assume(hc, M):
+    """The scans apply L_i and U_i through their non-zeros only: L = diag + column 6 (rows 0..5) + [6][5]; U = diag(rows 0..5) +
+    [6][5] (csrc/meth_dae_elem.h, the coefficient row of a node).  Anything else in the product's Jacobian would be dropped."""
+    cond = M.load_conditions(os.path.join(ROOT, "tests", "golden", "methanation_information.csv"))
+    guess = M.initial_guess(cond)
+    rs = np.random.RandomState(2)
+    p = M.p0_tuple(cond, 3, M.BASEPARAMS)
+    y = guess[3] * (1 + 0.05 * rs.standard_normal(NS))
+    Lb, D, Ub = _blocks(_matrix(hc, y, rs.standard_normal(NS) * 1e-2 * np.abs(y), p, 50.0))
+    okL = np.eye(7, dtype=bool)
+    okL[:6, 6] = True
+    okL[6, 5] = True
+    okU = np.zeros((7, 7), dtype=bool)
+    okU[np.arange(6), np.arange(6)] = True
+    okU[6, 5] = True
+    for i in range(1, NX):
+        assert not np.any(Lb[i][~okL]), i
+    for i in range(NX - 1):
+        assert not np.any(Ub[i][~okU]), i
