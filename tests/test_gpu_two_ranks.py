@@ -44,7 +44,11 @@ def test_two_rank_run_follows_the_one_rank_run():
     one = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--particles-per-gpu", str(n), "--no-cpu-baseline")
     assert two["n_gpus"] == 2 and two["config"]["particles_total"] == n == one["config"]["particles_total"]
     assert two["scaling"] == "weak" and two["value"] > 0
+    assert two["rccl_ranks"] == 2 and len(two["per_rank_ms_per_step"]) == 2 and one["rccl_ranks"] == 0      # RCCL itself saw both ranks
     assert two["tempering_steps_per_run"] == one["tempering_steps_per_run"]
+    # the Metropolis loops ran with their control on the device: identical decisions on both ranks mean identical loop lengths,
+    # and the all-reduces of the speculatively enqueued sweeps stayed matched (the run would hang or diverge otherwise)
+    assert two["mutation_sweeps"] == one["mutation_sweeps"] and two["mh_loop_synchronisations"] == one["mh_loop_synchronisations"]
     assert abs(two["logZ"][0] - one["logZ"][0]) < 1e-6 * abs(one["logZ"][0]) + 1e-6
     for a, b in zip(two["posterior_mean"], one["posterior_mean"]):
         assert abs(a - b) < 1e-3 * abs(b)      # the two-rank line reports rank 0's half of the population
