@@ -4,6 +4,7 @@
 // points operating on host buffers.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 
@@ -11,6 +12,7 @@
 #include "meth_dae.h"
 #include "meth_dae_wave.h"
 #include "meth_dae_elem.h"
+#include "meth_dae_split.h"
 #include "meth_model.h"
 
 namespace smc {
@@ -192,6 +194,60 @@ dae_elem_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
     if (split && lane == 0) atomicAdd(&counters[7], 1ULL);
 }
 
+
+// K8 v4: one solve per workgroup of two waves, each wave one half of the reactor (meth_dae_split.h).  Wave 0 takes the next
+// solve from the atomic counter and hands its index to wave 1 through LDS.
+__global__ void __launch_bounds__(kSplitThreads, 2)
+dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0_all, int64_t n_solves, double tf,
+                 double rtol, double atol, double h0, int max_attempts, double S, double P_stp,
+                 double *__restrict__ flows, double *__restrict__ y_final, int *__restrict__ status,
+                 unsigned long long *__restrict__ counters) {
+    extern __shared__ double lds[];  // kLdsSplitDoubles
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const SplitLane SL(wave, lane);
+    const DViewE D{lds + kLdsD, SL.node};
+    double *job = lds + kLdsJob;
+    unsigned split = 0;
+    for (int64_t it = 0; it <= n_solves; ++it) {
+        if (wave == 0) {
+            const int64_t nxt = wave_dequeue(&counters[5], lane, split);
+            job[0] = (double)nxt;      // every lane stores the same word (no lane branch in front of the barrier)
+        }
+        __syncthreads();
+        const int64_t sidx = (int64_t)wave_uniform(job[0]);
+        if (sidx >= n_solves) break;
+        double p[18];
+        for (int q = 0; q < 18; ++q) p[q] = p0_all[sidx * 18 + q];
+        if (SL.active)
+            for (int f = 0; f < 7; ++f) {
+                D(0, f) = y0_all[sidx * kNS + f * kNX + SL.node];
+                for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
+            }
+        DaeStats st;
+        dae_split_integrate(lds, wave, lane, p, tf, rtol, atol, h0, max_attempts, st);
+        if (SL.active && SL.node == kNX - 1) {
+            const double u = D(0, 6), T = D(0, 5);
+            const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
+            for (int f = 0; f < 5; ++f) {
+                const double cc = D(0, f);
+                flows[sidx * 5 + f] = (st.status == 0)
+                                          ? cc * S * u * 60 * k::R * T / (P_total) * 1e6 * (P_total) / P_stp * 298 / T
+                                          : -10000.0;
+            }
+            status[sidx] = st.status;
+            atomicAdd(&counters[0], (unsigned long long)st.steps);
+            atomicAdd(&counters[1], (unsigned long long)st.rejects);
+            atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
+            atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
+            atomicAdd(&counters[6], 1ULL);   // finished solves
+        }
+        if (y_final && SL.active)
+            for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + SL.node] = D(0, f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (split && wave == 0 && lane == 0) atomicAdd(&counters[7], 1ULL);
+}
+
 }  // namespace meth
 }  // namespace smc
 
@@ -284,6 +340,7 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     MH(hipGetDeviceProperties(&prop, device));
     const bool v1 = getenv("SMC_METH_DAE_V1") != nullptr;   // debug: the thread-per-solve version (meth_dae.h)
     const bool v2 = getenv("SMC_METH_DAE_V2") != nullptr;   // debug: lane = node scans (meth_dae_wave.h)
+    const bool v4 = smc::meth_split_enabled();               // two waves per solve (meth_dae_split.h)
     const int budget = getenv("SMC_METH_MAX_ATTEMPTS") ? atoi(getenv("SMC_METH_MAX_ATTEMPTS")) : kDaeMaxAttempts;
     int64_t nslots = ((n_solves + 63) / 64) * 64;
     const int64_t max_slots = (int64_t)prop.multiProcessorCount * 256;   // 4 waves per CU
@@ -308,6 +365,19 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     if (v1) {
         hipLaunchKernelGGL(dae_kernel, dim3((unsigned)(nslots / 64)), dim3(64), 0, 0, dws, nslots, dp, dy0, n_solves, tf,
                            rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
+    } else if (v4 && !v2) {
+        const int gpc = getenv("SMC_METH_WAVES_PER_CU") ? atoi(getenv("SMC_METH_WAVES_PER_CU")) : 4;   // workgroups (solves) per CU
+        int64_t ngroups = (int64_t)prop.multiProcessorCount * (gpc >= 1 && gpc <= 4 ? gpc : 4);
+        if (ngroups > n_solves) ngroups = n_solves;
+        if (getenv("SMC_K8_SPLIT_DEBUG")) {
+            int nb = -1, nb3 = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dae_split_kernel, kSplitThreads, kLdsSplitDoubles * sizeof(double));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, dae_elem_kernel, 64, kLdsDoubles * sizeof(double));
+            fprintf(stderr, "[k8 split] resident workgroups per CU: v4 %d (LDS %zu B), v3 %d (LDS %zu B); shared memory per CU %zu B\n", nb,
+                    kLdsSplitDoubles * sizeof(double), nb3, kLdsDoubles * sizeof(double), (size_t)prop.maxSharedMemoryPerMultiProcessor);
+        }
+        hipLaunchKernelGGL(dae_split_kernel, dim3((unsigned)ngroups), dim3(kSplitThreads), kLdsSplitDoubles * sizeof(double), 0, dp,
+                           dy0, n_solves, tf, rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
     } else if (!v2) {
         // one wave per SIMD is all that fits (512 VGPRs and 38.8 KB of LDS per wave); SMC_METH_WAVES_PER_CU < 4 thins the grid
         // for the occupancy-scaling measurement of profiles/r02_k8_occupancy.md
