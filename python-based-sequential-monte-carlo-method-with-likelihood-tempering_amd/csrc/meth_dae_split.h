@@ -1,28 +1,30 @@
-// meth_dae_split.h -- K8 v4: one solve per WORKGROUP OF TWO WAVES; each wave owns one half of the reactor.
+// meth_dae_split.h -- K8 v4: one solve per WORKGROUP OF TWO WAVES; the two elimination chains get a wave each.
 //
 // Why.  v3 (meth_dae_elem.h) keeps the block factors of all 51 nodes in one wave's registers: 2 x 51 doubles per lane = 204 of its
-// 472 VGPRs, so one wave per SIMD is all that fits, and the vector ALUs of that SIMD are busy 43 % of the cycles
+// 472 VGPRs, so one wave per SIMD is all that fits, and that wave executes vector instructions in 50 % of its cycles
 // (profiles/r04_k8_pmc_sq_summary.json): a dependent FP64 instruction waits for its predecessor and nothing else is there to
 // issue.  The two-ended elimination of round 4 put two chains into the one instruction stream; they cost 1.5 - 1.7 x a single
 // chain, i.e. the stream is then mostly issue-bound - the second chain is not free.  Here the two chains get a wave each:
-//   wave 0: nodes 0 .. 25  (chain downwards 0 -> 24, and the middle node 25)          wave 1: nodes 26 .. 50 (chain upwards 50 -> 26)
-// Each wave holds HALF of the factors (26 + 25 doubles per lane), which brings the kernel under 256 VGPRs: two waves per SIMD,
-// eight per CU, with the same four solves per CU as before (the LDS of a solve is shared by its two waves).  The hardware then
-// interleaves two waves per SIMD cycle by cycle, which is what the hand-interleaved pair could only approximate.
-//   * everything that is parallel over nodes (predictor, residual, Jacobian, norms, difference updates) runs in BOTH waves on
-//     the wave's own nodes (lane = node - 26 w); the neighbour across the cut (node 25 <-> 26) comes through 7 LDS words;
+//   wave 0 ("main"):   the integrator of v3 - predictor, residuals, norms, error tests over all 51 nodes (lane = node) - and the
+//                      downward chain 0 -> 24 with the middle node 25;
+//   wave 1 ("server"): the upward chain 50 -> 26, on wave 0's commands (FACTOR: Jacobian blocks of nodes 26 .. 50 from the
+//                      differences array, transposition, elimination;  SOLVE: inward and outward scan of one right-hand side).
+// Each wave holds HALF of the factors (26 + 25 doubles per lane), which brings the kernel to 256 VGPRs: two waves per SIMD, eight
+// per CU, with the same four solves per CU as before (the LDS of a solve is shared by its two waves).
 //   * chain position k is node k in wave 0 and node 50 - k in wave 1: same parity, same lane layout, and - with the coefficient
 //     masks in the per-lane LDS ADDRESSES (SplitOffsets) - the SAME instruction stream: downwards the coupling is
 //     L_i G_{i-1}, upwards U_i H_{i+1}, and both are  c1[mr] g[mr][mc] + c2[mr] g[mr < 6 ? 6 : 5][mc]  with the right slots;
 //   * the waves meet at node 25: H_26 and X_25 cross through one 64-word LDS row, z_24 / w_26 through 2 x 7 words, and both
-//     waves solve the middle node redundantly (no second barrier before the solution runs outwards);
-//   * control flow is IDENTICAL in both waves by construction: every norm is the sum  s_0 + s_1  of the two waves' partial sums
-//     taken from LDS in that fixed order, flags cross the same way, so both waves take the same branches and meet at the same
-//     s_barrier (P after the predictor, F1 / F2 around the middle factor, A after the inward scan, C after the outward scan, E at
-//     the error test).  Every slot that crosses is written before one barrier and read after it, and not rewritten before the next.
-// Arithmetic per node is that of the two-ended v3 (same formulas, same order); only the norms are summed in a different order
-// (per wave, then the two), so results agree with v3 to the solver's tolerance, not to the bit.  PARITY UNPINNED against the
-// reference's IDA like every K8 version (see meth_dae.h); checked against v3 / v2 and the CPU checker.
+//     waves solve the middle node redundantly (no extra barrier before the solution runs outwards);
+//   * synchronisation is a command protocol with a FIXED number of s_barriers per command (FACTOR: dispatch, F1, F2;  SOLVE:
+//     dispatch, A, C;  QUIT: dispatch), so the two waves cannot disagree on the next barrier: wave 1 takes no decision of its
+//     own.  Every word that crosses is written before one barrier and read after it, and not rewritten before the next.
+// (A first version ran everything that is parallel over nodes in BOTH waves on half the nodes each: correct, but 1.45 x the
+// vector instructions of v3 and 6 % slower - with two waves per SIMD the instruction count is what matters.  Here wave 1 is
+// idle while wave 0 evaluates residuals and norms, and the SIMD's other wave has the issue slots.)
+// Arithmetic per node and per norm is that of the two-ended v3, operation by operation (the masked coefficient of the unified
+// chain step multiplies by an exact zero), so v4 reproduces v3 BIT FOR BIT (tools/meth_v3_check.py N v4 v3).  PARITY UNPINNED
+// against the reference's IDA like every K8 version (see meth_dae.h).
 #pragma once
 #include <cstdlib>
 
@@ -37,25 +39,15 @@ inline bool meth_split_enabled() {
 namespace meth {
 
 constexpr int kSplitThreads = 128;
-constexpr int kCut = kMid + 1;                   // wave 0: nodes 0 .. 25, wave 1: nodes 26 .. 50
+constexpr int kCut = kMid + 1;                   // wave 0 eliminates nodes 0 .. 24 and the middle node 25, wave 1 nodes 50 .. 26
 constexpr int kLdsXch = kLdsDoubles;             // 64: H_26 in element layout (wave 1 -> 0), then X_25 (wave 0 -> 1)
-constexpr int kLdsYb = kLdsXch + 64;             // [owner wave][predictor | current][7]: unknowns of the boundary nodes 25 / 26
-constexpr int kLdsMid = kLdsYb + 28;             // [wave][8]: z_24 / w_26 (slot 7: the lanes that hold no result)
-constexpr int kLdsNwt = kLdsMid + 16;            // [wave][2]: Newton norm partial sum, flags
-constexpr int kLdsErr = kLdsNwt + 4;             // [wave][3]: error-test partial sums (order, order - 1, order + 1)
-constexpr int kLdsFac = kLdsErr + 6;             // [2]: factorisation flags
-constexpr int kLdsJob = kLdsFac + 2;             // [2]: queue position, cancelled flag (kernels' work hand-out)
-constexpr int kLdsSplitDoubles = kLdsJob + 2;
+constexpr int kLdsMid = kLdsXch + 64;            // [wave][8]: z_24 / w_26 (slot 7: the lanes that hold no result)
+constexpr int kLdsFac = kLdsMid + 16;            // [2]: factorisation flags
+constexpr int kLdsCmd = kLdsFac + 2;             // [4]: command, c = h / alpha, order, -
+constexpr int kLdsPar = kLdsCmd + 4;             // [18]: the solve's parameters (wave 1 evaluates the Jacobian blocks of its nodes)
+constexpr int kLdsSplitDoubles = kLdsPar + 18;
 static_assert(kLdsSplitDoubles * 8 * 4 <= 160 * 1024, "four solves per CU");
-
-struct SplitLane {
-    int w, lane, node;      // wave of the workgroup, lane of the wave, node held in node layout
-    bool active;            // the lane holds a node
-    bool take_m, take_p;    // its lower / upper neighbour lives in the other wave
-    __device__ __forceinline__ SplitLane(int w_, int l) : w(w_), lane(l), node(w_ ? kCut + l : l), active(l < (w_ ? kNX - kCut : kCut)),
-                                                          take_m(w_ == 1 && l == 0), take_p(w_ == 0 && l == kCut - 1) {}
-    __device__ __forceinline__ int chain_node(int k) const { return w ? kNX - 1 - k : k; }
-};
+enum : int { kCmdQuit = 0, kCmdFactor = 1, kCmdSolve = 2 };
 
 __device__ __forceinline__ void split_barrier() { __syncthreads(); }
 // The lane index as a value the compiler cannot see through: what is derived from it (row / column indices, LDS offsets, masks) is
@@ -65,15 +57,14 @@ __device__ __forceinline__ int opaque_lane(int lane) {
     asm volatile("" : "+v"(lane));
     return lane;
 }
-
-// unknowns of the neighbouring nodes: wave shuffles, and the other wave's boundary node from LDS (yb: its 7 words; a broadcast read)
-__device__ __forceinline__ void split_neighbours(const SplitLane &S, const double *w0, const double *yb, double *wm, double *wp) {
-    SMC_UNROLL
-    for (int f = 0; f < 7; ++f) {
-        const double lo = __shfl_up(w0[f], 1), hi = __shfl_down(w0[f], 1), far = yb[f];
-        wm[f] = S.take_m ? far : lo;
-        wp[f] = S.take_p ? far : hi;
-    }
+// wave 0 -> wave 1: the next thing to do.  Every lane stores the same words (no lane branch in front of the barrier); the
+// barrier publishes them together with whatever wave 0 wrote for the command (right-hand side, parameters, differences).
+__device__ __forceinline__ void split_command(double *lds, int cmd, double c, int order) {
+    double *slot = lds + kLdsCmd;
+    slot[0] = (double)cmd;
+    slot[1] = c;
+    slot[2] = (double)order;
+    split_barrier();
 }
 
 // per lane and node parity: where in a node's coefficient row (meth_dae_elem.h: [0..6] ld, [7] 0, [8..14] lx, [15] 0, [16..21] ud,
@@ -243,26 +234,29 @@ struct SplitBackward {
     }
 };
 
-// iteration matrix at the predictor (own nodes), transposition into the element layout, the wave's chain, the middle node
-__device__ __forceinline__ bool split_build_and_factor(const SplitLane &S, double *lds, const double *yp,
+// Iteration matrix at the predictor, transposition into the element layout, the wave's chain, the middle node.  Both waves:
+// wave 0 holds node `lane` (its predictor and psi are the integrator's), wave 1 holds node 25 + lane (lane 0: node 25, only as
+// the neighbour of node 26) with predictor and psi recomputed from the differences array.  evals: the lane evaluates a node and
+// writes its coefficient and staging rows (wave 0: nodes 0 .. 25; its lanes 26 .. 50 run along for nothing).
+__device__ __forceinline__ bool split_build_and_factor(int w, int lane_in, int node, bool evals, double *lds, const double *yp,
                                                        const double *psi, const double *p, double c, double (&X)[kMid + 1],
                                                        double (&G)[kMid]) {
     const double cj = 1.0 / c;
-    const SplitChain C(S.w, opaque_lane(S.lane));
+    const SplitChain C(w, opaque_lane(lane_in));
     const ElemLane &L = C.L;
     double *cf = lds + kLdsCf, *stage = lds + kLdsB, *xch = lds + kLdsXch, *fac = lds + kLdsFac;
     {
         double wm[7], wp[7], yd0[7], res[7], Lb[kNB], Db[kNB], Ub[kNB];
-        split_neighbours(S, yp, lds + kLdsYb + (1 - S.w) * 14, wm, wp);
+        neighbours(yp, wm, wp);
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) yd0[f] = psi[f] * cj;
         SMC_UNROLL
         for (int q = 0; q < kNB; ++q) Lb[q] = Db[q] = Ub[q] = 0.0;
-        if (S.active) node_eval<true>(S.node, wm, yp, wp, yd0, p, cj, res, Lb, Db, Ub);
+        if (evals) node_eval<true>(node, wm, yp, wp, yd0, p, cj, res, Lb, Db, Ub);
         SMC_UNROLL
         for (int i = 0; i <= kMid; ++i) X[i] = 0.0;
-        if (S.active) {
-            double *o = cf + S.node * kCfRow;
+        if (evals) {
+            double *o = cf + node * kCfRow;
             SMC_UNROLL
             for (int r = 0; r < 7; ++r) {
                 o[r] = Lb[r * 7 + r];
@@ -275,9 +269,9 @@ __device__ __forceinline__ bool split_build_and_factor(const SplitLane &S, doubl
         }
         SMC_UNROLL
         for (int rho = 0; rho < 7; ++rho) {   // one block row of the wave's nodes per pass through its part of the staging row
-            if (S.active)
+            if (evals)
                 SMC_UNROLL
-                for (int cc = 0; cc < 7; ++cc) stage[S.node * 7 + cc] = Db[rho * 7 + cc];
+                for (int cc = 0; cc < 7; ++cc) stage[node * 7 + cc] = Db[rho * 7 + cc];
             wave_lds_sync();
             if (L.r == rho && L.c < 7)        // even positions: lane (r, c) holds [r][c]
                 SMC_UNROLL
@@ -285,66 +279,45 @@ __device__ __forceinline__ bool split_build_and_factor(const SplitLane &S, doubl
             if (L.c == rho && L.r < 7) {      // odd positions (and the odd middle node, wave 0): lane (r, c) holds [c][r]
                 SMC_UNROLL
                 for (int k = 1; k < kMid; k += 2) X[k] = stage[C.node(k) * 7 + L.r];
-                if (S.w == 0) X[kMid] = stage[kMid * 7 + L.r];
+                if (w == 0) X[kMid] = stage[kMid * 7 + L.r];
             }
             wave_lds_sync();
         }
     }
     int ok = SplitFactorLoop<kMid - 1>::run(C, cf, X, G);
     ok = __all(ok);
-    if (S.w) {
-        xch[S.lane] = G[kMid - 1];       // H_26
-        if (S.lane == 0) fac[1] = (double)ok;
+    if (w) {
+        xch[L.lane] = G[kMid - 1];       // H_26
+        fac[1] = (double)ok;             // (every lane the same word)
     }
     split_barrier();                     // F1
-    if (S.w == 0) {
+    if (w == 0) {
         ok &= split_factor_middle(L, cf, xch, X, G);
         ok = __all(ok) & (int)(fac[1] != 0.0);
-        xch[S.lane] = X[kMid];           // (H_26 has been read: same wave, LDS in order)
-        if (S.lane == 0) fac[0] = (double)ok;
+        xch[L.lane] = X[kMid];           // (H_26 has been read: same wave, LDS in order)
+        fac[0] = (double)ok;
     }
     split_barrier();                     // F2
-    if (S.w) X[kMid] = xch[S.lane];
+    if (w) X[kMid] = xch[L.lane];
     return __builtin_amdgcn_readfirstlane((int)(fac[0] != 0.0)) != 0;
 }
 
-// one modified-Newton iteration; returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
-__device__ __forceinline__ double split_newton_iteration(const SplitLane &S, double *lds, double *y, double *dd,
-                                                         const double *psi, const double *p, double c, double rtol,
-                                                         double atol, const double (&X)[kMid + 1], const double (&G)[kMid]) {
-    const double cj = 1.0 / c;
-    const SplitChain C(S.w, opaque_lane(S.lane));
+// The linear solve of one Newton iteration, both waves (after the command's barrier: the right-hand side is in LDS): inwards on
+// the wave's chain, barrier A, the middle node in both waves, outwards, barrier C.
+__device__ __forceinline__ void split_solve(int w, int lane_in, double *lds, const double (&X)[kMid + 1], const double (&G)[kMid]) {
+    const SplitChain C(w, opaque_lane(lane_in));
     const ElemLane &L = C.L;
-    double *b = lds + kLdsB, *z = lds + kLdsZ, *mid = lds + kLdsMid, *nwt = lds + kLdsNwt, *ybo = lds + kLdsYb + S.w * 14 + 7;
+    double *b = lds + kLdsB, *z = lds + kLdsZ, *mid = lds + kLdsMid;
     const double *cf = lds + kLdsCf;
-    int finite = 1;
     {
-        double wm[7], wp[7], yd0[7], res[7];
-        split_neighbours(S, y, lds + kLdsYb + (1 - S.w) * 14 + 7, wm, wp);
-        SMC_UNROLL
-        for (int f = 0; f < 7; ++f) yd0[f] = (psi[f] + dd[f]) * cj;
-        if (S.active) {
-            node_eval<false>(S.node, wm, y, wp, yd0, p, cj, res, nullptr, nullptr, nullptr);
-            SMC_UNROLL
-            for (int r = 0; r < 7; ++r) {
-                if (!(res[r] - res[r] == 0.0)) finite = 0;
-                b[S.node * 7 + r] = -res[r];
-            }
-        }
-    }
-    finite = __all(finite);
-    if (S.lane == 0) nwt[S.w * 2 + 1] = (double)finite;
-    wave_lds_sync();
-    {   // inward on the wave's chain
         SplitOperands op{};
         op.b = b[C.node(0) * 7 + C.o0.b];
         const double zl = SplitForward<0>::run(C, cf, b, z, X, 0.0, op);
         constexpr int Q = (kMid - 1) & 1;
         const int mr = L.template mr<Q>(), mc = L.template mc<Q>();
-        mid[S.w * 8 + ((mc == 0 && mr < 7) ? mr : 7)] = zl;
+        mid[w * 8 + ((mc == 0 && mr < 7) ? mr : 7)] = zl;
     }
-    split_barrier();                     // A: z_24, w_26, b_25 and both finite flags are visible
-    if (!__builtin_amdgcn_readfirstlane((int)(nwt[1] != 0.0) & (int)(nwt[3] != 0.0))) return -1.0;      // the same words in both waves: the same branch
+    split_barrier();                     // A: z_24 and w_26 are visible
     {   // the middle node, in both waves:  x_25 = X_25 (b_25 - L_25 z_24 - U_25 w_26)
         constexpr int I = kMid, Q = I & 1;
         const int mr = L.template mr<Q>(), mc = L.template mc<Q>(), c6 = min6(mc);
@@ -356,40 +329,101 @@ __device__ __forceinline__ double split_newton_iteration(const SplitLane &S, dou
         const int mrn = min6(L.template mr<1 - Q>());
         const double zK = z[C.node(kMid - 1) * kZRow + mrn];      // own z_24 / w_26 on the row index
         const double xm = allsum_over_mc<Q>(X[I] * t);
-        if (S.w == 0) z[I * kZRow + ((mc == 0 && mr < 7) ? mr : 7)] = xm;
+        if (w == 0) z[I * kZRow + ((mc == 0 && mr < 7) ? mr : 7)] = xm;
         SplitBackward<kMid - 1>::run(C, z, G, xm, zK);
     }
-    wave_lds_sync();
+    split_barrier();                     // C: the whole solution is in LDS
+}
+
+// one modified-Newton iteration (wave 0); returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
+__device__ __forceinline__ double split_newton_iteration(int lane, double *lds, double *y, double *dd, const double *psi,
+                                                         const double *p, double c, double rtol, double atol,
+                                                         const double (&X)[kMid + 1], const double (&G)[kMid]) {
+    const double cj = 1.0 / c;
+    const bool node = lane < kNX;
+    double *b = lds + kLdsB, *z = lds + kLdsZ;
+    int finite = 1;
+    {
+        double wm[7], wp[7], yd0[7], res[7];
+        neighbours(y, wm, wp);
+        SMC_UNROLL
+        for (int f = 0; f < 7; ++f) yd0[f] = (psi[f] + dd[f]) * cj;
+        if (node) {
+            node_eval<false>(lane, wm, y, wp, yd0, p, cj, res, nullptr, nullptr, nullptr);
+            SMC_UNROLL
+            for (int r = 0; r < 7; ++r) {
+                if (!(res[r] - res[r] == 0.0)) finite = 0;
+                b[lane * 7 + r] = -res[r];
+            }
+        }
+    }
+    if (!__all(finite)) return -1.0;     // (no command: wave 1 stays at its barrier)
+    split_command(lds, kCmdSolve, c, 0);
+    split_solve(0, lane, lds, X, G);
     double sumsq = 0.0;
-    if (S.active)
+    if (node)
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) {
-            const double dx = z[S.node * kZRow + f];
+            const double dx = z[lane * kZRow + f];
             const double sc = atol + rtol * fabs(y[f] - dd[f]);      // the predictor: y = yp + dd (kept as y and dd only - 14 VGPRs)
             const double q = dx * recip1(sc);
             sumsq += q * q;
             y[f] += dx;
             dd[f] += dx;
         }
-    if (S.take_m || S.take_p)            // the boundary node's new unknowns for the other wave's next residual
-        SMC_UNROLL
-        for (int f = 0; f < 7; ++f) ybo[f] = y[f];
-    const double part = allsum_wave(sumsq);
-    if (S.lane == 0) nwt[S.w * 2] = part;
-    split_barrier();                     // C
-    return sqrt(wave_uniform(nwt[0] + nwt[2]) / kNS);
+    wave_lds_sync();
+    return sqrt(allsum_wave(sumsq) / kNS);
 }
 
-// Integrate one solve (both waves of the workgroup call this with the same arguments).  lds: the workgroup's region of
-// kLdsSplitDoubles doubles, holding y0 in row 0 of the differences array and zeros in rows 1..7 on entry (written by the
-// owners of the nodes, followed by a barrier); the state at tf is left in row 0.
-__device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int lane, const double *p, double tf, double rtol,
-                                                    double atol, double h0, int max_attempts, DaeStats &st) {
+// Wave 1: serves the commands of wave 0 until it is told to quit (the kernel is over).  It keeps the factors of its chain
+// between commands and nothing else.
+__device__ __forceinline__ void dae_split_server(double *lds, int lane) {
+    double X[kMid + 1], G[kMid];
+    const double *slot = lds + kLdsCmd, *par = lds + kLdsPar;
+    for (;;) {
+        split_barrier();
+        const int cmd = __builtin_amdgcn_readfirstlane((int)slot[0]);
+        if (cmd == kCmdQuit) break;
+        if (cmd == kCmdFactor) {
+            const double c = wave_uniform(slot[1]);
+            const int order = __builtin_amdgcn_readfirstlane((int)slot[2]);
+            double p[18];
+            SMC_UNROLL
+            for (int q = 0; q < 18; ++q) p[q] = wave_uniform(par[q]);
+            // predictor and psi of node 25 + lane from the differences array, as the integrator forms them (bdf.py:328-333)
+            const int node = kMid + lane;
+            const bool has = lane <= kNX - 1 - kMid;
+            const DViewE D{lds + kLdsD, has ? node : kMid};
+            double yp[7], psi[7], q7[7];
+            SMC_UNROLL
+            for (int f = 0; f < 7; ++f) yp[f] = q7[f] = 0.0;
+            SMC_UNROLL
+            for (int kk = 0; kk <= kMaxOrder; ++kk)
+                if (kk <= order)
+                    SMC_UNROLL
+                    for (int f = 0; f < 7; ++f) {
+                        const double dv = D(kk, f);
+                        yp[f] += dv;
+                        if (kk >= 1) q7[f] += dv * bdf_gamma(kk);
+                    }
+            const double inv_alpha = 1.0 / bdf_alpha(order);
+            SMC_UNROLL
+            for (int f = 0; f < 7; ++f) psi[f] = q7[f] * inv_alpha;
+            (void)split_build_and_factor(1, lane, node, has && lane >= 1, lds, yp, psi, p, c, X, G);
+        } else {
+            split_solve(1, lane, lds, X, G);
+        }
+    }
+}
+
+// Integrate one solve (wave 0; wave 1 is in dae_split_server).  lds: the workgroup's region of kLdsSplitDoubles doubles, holding
+// y0 in row 0 of the differences array, zeros in rows 1..7 and the parameters in the kLdsPar row on entry; the state at tf is
+// left in row 0.  Time stepping, Newton control and error tests: meth_dae_elem.h (dae_elem_integrate), line by line.
+__device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const double *p, double tf, double rtol, double atol,
+                                                    double h0, int max_attempts, DaeStats &st) {
     const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
-    const SplitLane S(wave, lane);
-    const bool node = S.active;
-    const DViewE D{lds + kLdsD, S.node};
-    double *err = lds + kLdsErr, *ybo = lds + kLdsYb + S.w * 14;
+    const bool node = lane < kNX;
+    const DViewE D{lds + kLdsD, lane};
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
     st.status = 0;
     double t = 0.0, h_abs = h0;
@@ -443,15 +477,12 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int l
                 psi[f] = q[f] * inv_alpha;
                 dd[f] = 0.0;
             }
-            if (S.take_m || S.take_p)
-                SMC_UNROLL
-                for (int f = 0; f < 7; ++f) ybo[f] = ybo[7 + f] = s[f];
         }
-        split_barrier();                 // P: the boundary nodes' predictors are visible
         const bool fresh = !lu_valid || c != c_lu || force_rebuild;
         if (fresh) {
             ++st.nlu;
-            lu_valid = split_build_and_factor(S, lds, y, psi, p, c, X, G);      // y is the predictor here
+            split_command(lds, kCmdFactor, c, order);
+            lu_valid = split_build_and_factor(0, lane, lane, lane < kCut, lds, y, psi, p, c, X, G);      // y is the predictor here
             c_lu = c;
             force_rebuild = false;
         }
@@ -461,7 +492,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int l
             double dy_norm_old = -1.0;
 #pragma unroll 1
             for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
-                const double dy_norm = split_newton_iteration(S, lds, y, dd, psi, p, c, rtol, atol, X, G);
+                const double dy_norm = split_newton_iteration(lane, lds, y, dd, psi, p, c, rtol, atol, X, G);
                 n_iter = kk + 1;
                 ++st.newton_iters;
                 if (dy_norm < 0) break;
@@ -485,7 +516,6 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int l
             continue;
         }
         const double safety = 0.9 * (2 * kNewtonMaxIter + 1) / (2.0 * kNewtonMaxIter + n_iter);
-        const bool select = n_equal + 1 >= order + 1;
         double se = 0.0;
         if (node)
             SMC_UNROLL
@@ -494,12 +524,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int l
                 const double e = bdf_error_const(order) * dd[f] * isc;
                 se += e * e;
             }
-        {
-            const double part = allsum_wave(se);
-            if (S.lane == 0) err[S.w * 3] = part;
-        }
-        split_barrier();                 // E
-        const double error_norm = sqrt(wave_uniform(err[0] + err[3]) / (6 * kNX));
+        const double error_norm = sqrt(allsum_wave(se) / (6 * kNX));
         if (!(error_norm <= 1)) {
             ++st.rejects;
             const double factor = (error_norm == error_norm) ? fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1))) : 0.2;
@@ -511,6 +536,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int l
         ++n_equal;
         t = t_new;
         ++st.steps;
+        const bool select = n_equal >= order + 1;
         double sm = 0.0, sp = 0.0;
         if (node) {
             double acc[7], d_order[7], dnew2[7];
@@ -540,13 +566,8 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int l
                 }
         }
         if (!select) continue;
-        {
-            const double pm = allsum_wave(sm), pp = allsum_wave(sp);
-            if (S.lane == 0) { err[S.w * 3 + 1] = pm; err[S.w * 3 + 2] = pp; }
-        }
-        split_barrier();                 // E2 (steps that select the order: one in order + 1)
         const double inf = __longlong_as_double(0x7ff0000000000000LL);
-        const double em_s = sqrt(wave_uniform(err[1] + err[4]) / (6 * kNX)), ep_s = sqrt(wave_uniform(err[2] + err[5]) / (6 * kNX));
+        const double em_s = sqrt(allsum_wave(sm) / (6 * kNX)), ep_s = sqrt(allsum_wave(sp) / (6 * kNX));
         const double em = (order > 1) ? em_s : inf;
         const double ep = (order < kMaxOrder) ? ep_s : inf;
         const double fm = pow(em, -1.0 / order), f0 = pow(error_norm, -1.0 / (order + 1)), fp = pow(ep, -1.0 / (order + 2));
@@ -561,7 +582,6 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int wave, int l
         n_equal = 0;
     }
     st.status = __builtin_amdgcn_readfirstlane(st.status);
-    split_barrier();                     // the differences array is complete for whoever reads the result
 }
 
 }  // namespace meth

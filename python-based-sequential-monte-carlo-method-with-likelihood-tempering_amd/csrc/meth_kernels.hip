@@ -195,8 +195,8 @@ dae_elem_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
 }
 
 
-// K8 v4: one solve per workgroup of two waves, each wave one half of the reactor (meth_dae_split.h).  Wave 0 takes the next
-// solve from the atomic counter and hands its index to wave 1 through LDS.
+// K8 v4: one solve per workgroup of two waves (meth_dae_split.h): wave 0 runs the integrator and the downward chain, wave 1 serves
+// the upward chain.  Wave 0 takes the solves from the atomic counter; wave 1 only ever sees commands.
 __global__ void __launch_bounds__(kSplitThreads, 2)
 dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0_all, int64_t n_solves, double tf,
                  double rtol, double atol, double h0, int max_attempts, double S, double P_stp,
@@ -204,28 +204,28 @@ dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y
                  unsigned long long *__restrict__ counters) {
     extern __shared__ double lds[];  // kLdsSplitDoubles
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const SplitLane SL(wave, lane);
-    const DViewE D{lds + kLdsD, SL.node};
-    double *job = lds + kLdsJob;
+    if (wave) {
+        dae_split_server(lds, lane);
+        return;
+    }
+    const DViewE D{lds + kLdsD, lane};
     unsigned split = 0;
     for (int64_t it = 0; it <= n_solves; ++it) {
-        if (wave == 0) {
-            const int64_t nxt = wave_dequeue(&counters[5], lane, split);
-            job[0] = (double)nxt;      // every lane stores the same word (no lane branch in front of the barrier)
-        }
-        __syncthreads();
-        const int64_t sidx = (int64_t)wave_uniform(job[0]);
+        const int64_t sidx = wave_dequeue(&counters[5], lane, split);
         if (sidx >= n_solves) break;
         double p[18];
-        for (int q = 0; q < 18; ++q) p[q] = p0_all[sidx * 18 + q];
-        if (SL.active)
+        for (int q = 0; q < 18; ++q) {
+            p[q] = p0_all[sidx * 18 + q];
+            lds[kLdsPar + q] = p[q];
+        }
+        if (lane < kNX)
             for (int f = 0; f < 7; ++f) {
-                D(0, f) = y0_all[sidx * kNS + f * kNX + SL.node];
+                D(0, f) = y0_all[sidx * kNS + f * kNX + lane];
                 for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
             }
         DaeStats st;
-        dae_split_integrate(lds, wave, lane, p, tf, rtol, atol, h0, max_attempts, st);
-        if (SL.active && SL.node == kNX - 1) {
+        dae_split_integrate(lds, lane, p, tf, rtol, atol, h0, max_attempts, st);
+        if (lane == kNX - 1) {
             const double u = D(0, 6), T = D(0, 5);
             const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
             for (int f = 0; f < 5; ++f) {
@@ -239,13 +239,14 @@ dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y
             atomicAdd(&counters[1], (unsigned long long)st.rejects);
             atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
-            atomicAdd(&counters[6], 1ULL);   // finished solves
         }
-        if (y_final && SL.active)
-            for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + SL.node] = D(0, f);
+        if (y_final && lane < kNX)
+            for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + lane] = D(0, f);
+        if (lane == 0) atomicAdd(&counters[6], 1ULL);   // finished solves
         __builtin_amdgcn_wave_barrier();
     }
-    if (split && wave == 0 && lane == 0) atomicAdd(&counters[7], 1ULL);
+    split_command(lds, kCmdQuit, 0.0, 0);
+    if (split && lane == 0) atomicAdd(&counters[7], 1ULL);
 }
 
 }  // namespace meth

@@ -215,10 +215,8 @@ meth_particles_dae_kernel(MethModel m, const double *__restrict__ theta, int64_t
     if (split && lane == 0) atomicAdd(&counters->wave_split, 1ULL);
 }
 
-// The same sweep with TWO waves per solve (meth_dae_split.h: each wave one half of the reactor, two waves per SIMD).  Wave 0
-// takes the next position from the queue and decides the early rejection - the bound reads other solves' results while they
-// change, so only ONE wave may look - and hands {position, cancelled} to wave 1 through LDS; from there on both waves run the
-// same control flow.
+// The same sweep with TWO waves per solve (meth_dae_split.h): wave 0 is the kernel above with the downward chain only, wave 1
+// serves the upward chain on wave 0's commands (it never looks at the queue, the rejection bound or the results).
 __global__ void __launch_bounds__(kSplitThreads, 2)
 meth_particles_dae_split_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
                                 const int64_t *__restrict__ live, double *flows, int *status, const RejectArgs *__restrict__ rej,
@@ -226,64 +224,53 @@ meth_particles_dae_split_kernel(MethModel m, const double *__restrict__ theta, i
                                 unsigned long long *__restrict__ queue) {
     extern __shared__ double lds[];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const SplitLane SL(wave, lane);
-    const DViewE D{lds + kLdsD, SL.node};
-    double *job = lds + kLdsJob;
+    if (wave) {
+        dae_split_server(lds, lane);
+        return;
+    }
+    const DViewE D{lds + kLdsD, lane};
     const int64_t n_live = live ? (int64_t)queue[1] : n;
     const int64_t count = n_live * m.n_data;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters->expected_solves = (unsigned long long)count;
+    if (blockIdx.x == 0 && lane == 0) counters->expected_solves = (unsigned long long)count;
     unsigned split = 0;
     for (int64_t it = 0; it <= count; ++it) {
-        if (wave == 0) {
-            const int64_t q = wave_dequeue(&queue[0], lane, split);
-            int cancelled = 0;
-            if (q < count && rej) {
-                const int e_rank = (int)(q / n_live);
-                const int64_t particle = live ? live[q - (int64_t)e_rank * n_live] : q - (int64_t)e_rank * n_live;
-                double sigma = m.sigma_fixed;
-                if (m.est_sigma) {
-                    sigma = m.base[8];
-                    for (int kq = 0; kq < m.dim; ++kq)
-                        if (m.est_pos[kq] == 8) sigma = theta[kq * stride + particle];
-                }
-                cancelled = __builtin_amdgcn_readfirstlane((int)meth_certainly_rejected(rej, m.obs, m.n_data, sigma, particle, flows, status, lane));
-            }
-            job[0] = (double)q;            // every lane stores the same words: no lane branch in front of the barrier
-            job[1] = (double)cancelled;
-        }
-        __syncthreads();
-        const int64_t pos = (int64_t)wave_uniform(job[0]);
-        const int cancelled = __builtin_amdgcn_readfirstlane((int)job[1]);
+        const int64_t pos = wave_dequeue(&queue[0], lane, split);
         if (pos >= count) break;
         const int e_rank = (int)(pos / n_live);
         const int64_t j = pos - (int64_t)e_rank * n_live;
         const int e = order ? order[e_rank] : e_rank;
         const int64_t particle = live ? live[j] : j;
         const int64_t w = particle * m.n_data + e;
-        if (cancelled) {
-            if (wave == 0) {
+        if (rej) {
+            double sigma = m.sigma_fixed;
+            if (m.est_sigma) {
+                sigma = m.base[8];
+                for (int kq = 0; kq < m.dim; ++kq)
+                    if (m.est_pos[kq] == 8) sigma = theta[kq * stride + particle];
+            }
+            if (__builtin_amdgcn_readfirstlane((int)meth_certainly_rejected(rej, m.obs, m.n_data, sigma, particle, flows, status, lane))) {
                 __hip_atomic_store(status + w, kStatusCancelled, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 atomicAdd(&counters->cancelled_solves, lane == 0 ? 1ULL : 0ULL);
+                continue;
             }
-            __syncthreads();               // job[] is rewritten by wave 0 right after: wave 1 has read it
-            continue;
         }
         double p[18];
         for (int q = 0; q < 10; ++q) p[q] = m.cond[e * 10 + q];
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < 8; ++jj) {  // p_pred_bases[:, est_position] = particle (methanation_functions.py:80)
             double v = m.base[jj];
             for (int kq = 0; kq < m.dim; ++kq)
                 if (m.est_pos[kq] == jj) v = theta[kq * stride + particle];
             p[10 + jj] = v;
         }
-        if (SL.active)
+        for (int q = 0; q < 18; ++q) lds[kLdsPar + q] = p[q];      // for wave 1's Jacobian blocks (published by the first command)
+        if (lane < kNX)
             for (int f = 0; f < 7; ++f) {
-                D(0, f) = m.guess[(int64_t)e * kNS + f * kNX + SL.node];
+                D(0, f) = m.guess[(int64_t)e * kNS + f * kNX + lane];
                 for (int kk = 1; kk < 8; ++kk) D(kk, f) = 0.0;
             }
         DaeStats st;
-        dae_split_integrate(lds, wave, lane, p, m.tf, m.rtol, m.atol, m.h0, kDaeMaxAttempts, st);
-        if (SL.active && SL.node == kNX - 1) {
+        dae_split_integrate(lds, lane, p, m.tf, m.rtol, m.atol, m.h0, kDaeMaxAttempts, st);
+        if (lane == kNX - 1) {
             const double u = D(0, 6), T = D(0, 5);
             const double P_total = (p[0] + p[1] + p[2] + p[3] + p[4]) * k::R * p[5];
             for (int f = 0; f < 5; ++f) {
@@ -303,7 +290,8 @@ meth_particles_dae_split_kernel(MethModel m, const double *__restrict__ theta, i
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (split && wave == 0 && lane == 0) atomicAdd(&counters->wave_split, 1ULL);
+    split_command(lds, kCmdQuit, 0.0, 0);
+    if (split && lane == 0) atomicAdd(&counters->wave_split, 1ULL);
 }
 
 // my_loglike per particle from its 5 x n_data flows (:280-300); sigma = the particle's last estimated parameter
