@@ -156,8 +156,14 @@ MM_KERNEL_SOURCES = ("csrc/mm_kernels.hip", "csrc/mm_rk45.h", "csrc/rk45_math.h"
                      "csrc/sweep_args.h", "csrc/philox.h", "csrc/prior.h", "csrc/smc_internal.h", "include/smc_hip.h")
 
 
-# ... and of K8, the methanation DAE kernel (meth_smc.hip and everything it includes)
-K8_KERNEL_SOURCES = ("csrc/meth_smc.hip", "csrc/meth_dae_elem.h", "csrc/meth_dae_wave.h", "csrc/meth_dae.h", "csrc/meth_model.h",
+# ... and of K8, the methanation DAE kernel (meth_smc.hip and everything it includes).  The launches use the two-wave kernel
+# (meth_dae_split.h) unless SMC_K8_SPLIT=0 asks for the one-wave kernel of rounds 1-4 (bit-identical results, A/B runs)
+def k8_kernel_name():
+    return "meth_particles_dae_kernel" if os.environ.get("SMC_K8_SPLIT", "1") in ("0", "") else "meth_particles_dae_split_kernel"
+
+
+
+K8_KERNEL_SOURCES = ("csrc/meth_smc.hip", "csrc/meth_dae_split.h", "csrc/meth_dae_elem.h", "csrc/meth_dae_wave.h", "csrc/meth_dae.h", "csrc/meth_model.h",
                      "csrc/sweep_args.h", "csrc/philox.h", "csrc/prior.h", "csrc/smc_internal.h", "include/smc_hip.h")
 
 
@@ -450,7 +456,7 @@ def bench_methanation(args):
     k8 = {k: sum(o["stats"].get(k, 0) for o in outs) for k in ("bdf_steps", "newton_iters", "factorisations", "failed_solves")}
     k8_flop = k8["factorisations"] * FLOP_PER_FACTORISATION + k8["newton_iters"] * FLOP_PER_NEWTON_ITERATION
     # counter traffic of K8 per launch: only from a PMC summary of THIS kernel revision at THIS population (same rule as the MM line)
-    traffic, traffic_note = measured_traffic("smc::meth_particles_dae_kernel", n, family="k8")
+    traffic, traffic_note = measured_traffic("smc::" + k8_kernel_name(), n, family="k8")
     k8_launches = max(1, tm["solve"]["launches"])
     cpu = None if (args.no_cpu_baseline or world != 1) else cpu_baseline_methanation(pkg, cond, guess)
     print(json.dumps({
@@ -466,7 +472,7 @@ def bench_methanation(args):
         "tempering_steps_per_run": [o["step"] for o in outs], "mutation_sweeps": sweeps - args.steps,
         "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(), "posterior_std": outs[-1]["p_pred"].std(axis=0).tolist(),
         "logZ": [o["logZ"] for o in outs], "kernel_ms": tm,
-        "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF)", "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
+        "roofline": {"kernel": k8_kernel_name() + " (BDF solve per workgroup: integrator wave + chain-server wave)", "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
                      "achieved": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": k8_flop / (tm["solve"]["ms"] * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                      "device_counts": k8, "flop_per_factorisation": FLOP_PER_FACTORISATION,
@@ -523,7 +529,7 @@ def bench_methanation_sweeps(args, pkg, eng, s, n):
         "dae_solves_per_s": n * 30 / (tm["loglik"]["ms"] * 1e-3),      # from the unmasked initial sweep
         "accepted_per_sweep": acc, "note": "proposals outside the prior box are not solved (their share is 1 - accept-eligible)",
         "kernel_ms": tm,
-        "roofline": {"kernel": "meth_particles_dae_kernel (wave-per-solve BDF, element-layout scans)",
+        "roofline": {"kernel": k8_kernel_name() + " (BDF solve per workgroup, element-layout scans)",
                      "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
                      "achieved": k8_flop / (tm["loglik"]["ms"] * 1e-3) / 1e12,
                      "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",

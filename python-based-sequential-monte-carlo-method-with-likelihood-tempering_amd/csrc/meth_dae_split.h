@@ -31,10 +31,15 @@
 #include "meth_dae_elem.h"
 
 namespace smc {
-// which K8 the launches use: SMC_K8_SPLIT=1 selects the two-wave kernels of this header, 0 the one-wave kernels of meth_dae_elem.h
+// which K8 the launches use: the two-wave kernels of this header (default), or with SMC_K8_SPLIT=0 the one-wave kernels of
+// meth_dae_elem.h (same results bit for bit; kept for A/B runs)
 inline bool meth_split_enabled() {
     const char *e = getenv("SMC_K8_SPLIT");
-    return e ? atoi(e) != 0 : false;
+    return e ? atoi(e) != 0 : true;
+}
+inline int meth_split_role_policy() {   // SMC_K8_SPLIT_ROLES: 0 = wave 0 is the integrator (default), 1 = flipped by wave-slot parity, +4 = census
+    const char *e = getenv("SMC_K8_SPLIT_ROLES");
+    return e ? atoi(e) : 0;
 }
 namespace meth {
 
@@ -56,6 +61,25 @@ __device__ __forceinline__ void split_barrier() { __syncthreads(); }
 __device__ __forceinline__ int opaque_lane(int lane) {
     asm volatile("" : "+v"(lane));
     return lane;
+}
+// Which of the workgroup's two waves is the integrator ("main", role 0) and which the chain server (role 1).  The main wave
+// executes vector instructions about half of the time, the server a quarter, so every SIMD should hold one of each.  The
+// dispatcher already sees to that: with four 2-wave workgroups per CU the waves (0, 1) of the groups land on SIMDs (0, 2), (2, 1),
+// (1, 3), (3, 0) - one wave 0 and one wave 1 per SIMD on all 1024 SIMDs (census: SMC_K8_SPLIT_ROLES=4, one printf line per wave,
+// profiles/r04_k8_split_placement.txt) - so policy 0 (wave 0 integrates) is the default.  Policy 1 flips the roles with the
+// parity of wave 0's hardware slot (HW_REG_HW_ID bits 3:0); measured: it unbalances half of the SIMDs and is 1 - 2 % slower.
+__device__ __forceinline__ int split_role(double *lds, int wave_in_group, int policy) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID, bits 3:0 = WAVE_ID
+    if (wave_in_group == 0) lds[kLdsCmd + 3] = (double)hw;
+    split_barrier();
+    const int slot0 = __builtin_amdgcn_readfirstlane((int)lds[kLdsCmd + 3]);
+    const int role = wave_in_group ^ ((policy & 1) ? (slot0 & 1) : 0);
+    if ((policy & 4) && (threadIdx.x & 63) == 0) {   // placement census (SMC_K8_SPLIT_ROLES=4 / 5): one line per wave
+        const unsigned hwid = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4), xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+        printf("[k8 placement] group %u wave %d role %d xcc %u se %u cu %u simd %u slot %u\n", blockIdx.x, wave_in_group, role, xcc,
+               (hwid >> 13) & 7, (hwid >> 8) & 15, (hwid >> 4) & 3, hwid & 15);
+    }
+    return role;
 }
 // wave 0 -> wave 1: the next thing to do.  Every lane stores the same words (no lane branch in front of the barrier); the
 // barrier publishes them together with whatever wave 0 wrote for the command (right-hand side, parameters, differences).

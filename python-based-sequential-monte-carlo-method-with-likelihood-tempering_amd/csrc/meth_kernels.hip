@@ -201,10 +201,10 @@ __global__ void __launch_bounds__(kSplitThreads, 2)
 dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0_all, int64_t n_solves, double tf,
                  double rtol, double atol, double h0, int max_attempts, double S, double P_stp,
                  double *__restrict__ flows, double *__restrict__ y_final, int *__restrict__ status,
-                 unsigned long long *__restrict__ counters) {
+                 unsigned long long *__restrict__ counters, int role_policy) {
     extern __shared__ double lds[];  // kLdsSplitDoubles
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (wave) {
+    const int lane = threadIdx.x & 63;
+    if (split_role(lds, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), role_policy)) {
         dae_split_server(lds, lane);
         return;
     }
@@ -378,7 +378,7 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
                     kLdsSplitDoubles * sizeof(double), nb3, kLdsDoubles * sizeof(double), (size_t)prop.maxSharedMemoryPerMultiProcessor);
         }
         hipLaunchKernelGGL(dae_split_kernel, dim3((unsigned)ngroups), dim3(kSplitThreads), kLdsSplitDoubles * sizeof(double), 0, dp,
-                           dy0, n_solves, tf, rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt);
+                           dy0, n_solves, tf, rtol, atol, h0, budget, S, P_stp, dfl, dyf, dst, dcnt, smc::meth_split_role_policy());
     } else if (!v2) {
         // one wave per SIMD is all that fits (512 VGPRs and 38.8 KB of LDS per wave); SMC_METH_WAVES_PER_CU < 4 thins the grid
         // for the occupancy-scaling measurement of profiles/r02_k8_occupancy.md

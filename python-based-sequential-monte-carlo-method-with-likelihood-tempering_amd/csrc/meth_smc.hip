@@ -221,10 +221,10 @@ __global__ void __launch_bounds__(kSplitThreads, 2)
 meth_particles_dae_split_kernel(MethModel m, const double *__restrict__ theta, int64_t stride, int64_t n,
                                 const int64_t *__restrict__ live, double *flows, int *status, const RejectArgs *__restrict__ rej,
                                 const int *__restrict__ order, SweepCounters *__restrict__ counters,
-                                unsigned long long *__restrict__ queue) {
+                                unsigned long long *__restrict__ queue, int role_policy) {
     extern __shared__ double lds[];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    if (wave) {
+    const int lane = threadIdx.x & 63;
+    if (split_role(lds, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), role_policy)) {
         dae_split_server(lds, lane);
         return;
     }
@@ -503,7 +503,7 @@ static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int
     if (meth_split_enabled())   // two waves per solve: the same number of workgroups (four solves per CU), twice the waves
         hipLaunchKernelGGL(meth_particles_dae_split_kernel, dim3((unsigned)nwaves), dim3(meth::kSplitThreads),
                            meth::kLdsSplitDoubles * sizeof(double), ctx->stream, m, theta, stride, n, live, ctx->d_mflows,
-                           ctx->d_mstatus, reject ? ctx->d_reject : nullptr, order, ctx->d_counters, ctx->d_queue);
+                           ctx->d_mstatus, reject ? ctx->d_reject : nullptr, order, ctx->d_counters, ctx->d_queue, meth_split_role_policy());
     else
         hipLaunchKernelGGL(meth_particles_dae_kernel, dim3((unsigned)nwaves), dim3(64), kLdsDoubles * sizeof(double), ctx->stream,
                            m, theta, stride, n, live, ctx->d_mflows, ctx->d_mstatus, reject ? ctx->d_reject : nullptr, order,

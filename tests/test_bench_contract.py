@@ -108,11 +108,15 @@ def test_roofline_traffic_is_tied_to_kernel_revision_and_population(tmp_path, mo
     assert b is None and "another kernel revision" in note                  # another kernel build
 
 
-def test_k8_revision_hash_covers_the_dae_sources_only():
+def test_k8_revision_hash_covers_the_dae_sources_only(monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     assert bench.kernel_source_sha(family="k8") != bench.kernel_source_sha(family="mm")
-    assert any("meth_dae_elem.h" in f for f in bench.K8_KERNEL_SOURCES) and not any("mm_rk45" in f for f in bench.K8_KERNEL_SOURCES)
+    assert any("meth_dae_elem.h" in f for f in bench.K8_KERNEL_SOURCES) and any("meth_dae_split.h" in f for f in bench.K8_KERNEL_SOURCES)
+    monkeypatch.delenv("SMC_K8_SPLIT", raising=False)
+    assert bench.k8_kernel_name() == "meth_particles_dae_split_kernel"      # the two-wave kernel is what the launches use ...
+    monkeypatch.setenv("SMC_K8_SPLIT", "0")
+    assert bench.k8_kernel_name() == "meth_particles_dae_kernel"            # ... unless the one-wave kernel is asked for and not any("mm_rk45" in f for f in bench.K8_KERNEL_SOURCES)
 
 
 def test_measured_fp64_peak_comes_from_a_committed_probe_log(tmp_path, monkeypatch):

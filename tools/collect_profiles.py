@@ -60,9 +60,9 @@ def main():
         k8cmd = "python3 bench.py --workload methanation --particles-per-gpu 1024 --steps 1 --warmup 0 --no-cpu-baseline"
         subprocess.run([py, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(F, "k8_pmc_fetch"), os.path.join(F, "k8_pmc_write"),
                         os.path.join(P, f"{tag}_k8_pmc_fetch_write_summary.json"), "--particles-per-gpu", "1024", "--family", "k8",
-                        "--kernel", "meth_particles_dae_kernel", "--command", k8cmd], check=False)
+                        "--kernel", "meth_particles_dae_split_kernel", "--command", k8cmd], check=False)
         subprocess.run([py, os.path.join(ROOT, "tools", "pmc_sq_summary.py"), os.path.join(P, f"{tag}_k8_pmc_sq_summary.json"), "--kernel",
-                        "meth_particles_dae_kernel", "--family", "k8", "--command", k8cmd] +
+                        "meth_particles_dae_split_kernel", "--family", "k8", "--command", k8cmd] +
                        [os.path.join(F, f"k8_sq{i}") for i in (1, 2, 3, 4, 5, 6)], check=False)
 
 

@@ -28,8 +28,8 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_
 done
 cd $R
 log "summaries"
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/k8_pmc_fetch_write_summary.json --particles-per-gpu $N --family k8 --kernel meth_particles_dae_kernel --command "bench.py --workload methanation --particles-per-gpu $N --steps 1 --warmup 0 --no-cpu-baseline" | tee $O/traffic.txt
-python3 tools/pmc_sq_summary.py $O/k8_pmc_sq_summary.json $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/sq6 --kernel meth_particles_dae_kernel --family k8 --command "bench.py --workload methanation --particles-per-gpu $N --steps 1 --warmup 0 --no-cpu-baseline" | tee $O/sq.txt
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/k8_pmc_fetch_write_summary.json --particles-per-gpu $N --family k8 --kernel meth_particles_dae_split_kernel --command "bench.py --workload methanation --particles-per-gpu $N --steps 1 --warmup 0 --no-cpu-baseline" | tee $O/traffic.txt
+python3 tools/pmc_sq_summary.py $O/k8_pmc_sq_summary.json $O/sq1 $O/sq2 $O/sq3 $O/sq4 $O/sq5 $O/sq6 --kernel meth_particles_dae_split_kernel --family k8 --command "bench.py --workload methanation --particles-per-gpu $N --steps 1 --warmup 0 --no-cpu-baseline" | tee $O/sq.txt
 f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv
 log "done"
 tail -c 1500 $O/bench_methanation.json
