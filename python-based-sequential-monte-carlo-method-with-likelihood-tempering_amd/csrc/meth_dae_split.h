@@ -48,9 +48,8 @@ constexpr int kCut = kMid + 1;                   // wave 0 eliminates nodes 0 ..
 constexpr int kLdsXch = kLdsDoubles;             // 64: H_26 in element layout (wave 1 -> 0), then X_25 (wave 0 -> 1)
 constexpr int kLdsMid = kLdsXch + 64;            // [wave][8]: z_24 / w_26 (slot 7: the lanes that hold no result)
 constexpr int kLdsFac = kLdsMid + 16;            // [2]: factorisation flags
-constexpr int kLdsCmd = kLdsFac + 2;             // [4]: command, c = h / alpha, order, -
-constexpr int kLdsPar = kLdsCmd + 4;             // [18]: the solve's parameters (wave 1 evaluates the Jacobian blocks of its nodes)
-constexpr int kLdsSplitDoubles = kLdsPar + 18;
+constexpr int kLdsCmd = kLdsFac + 2;             // [4]: command, -, -, hardware id (split_role)
+constexpr int kLdsSplitDoubles = kLdsCmd + 4;
 static_assert(kLdsSplitDoubles * 8 * 4 <= 160 * 1024, "four solves per CU");
 enum : int { kCmdQuit = 0, kCmdFactor = 1, kCmdSolve = 2 };
 
@@ -81,13 +80,22 @@ __device__ __forceinline__ int split_role(double *lds, int wave_in_group, int po
     }
     return role;
 }
+// The solve's parameters as values the compiler cannot see through (they stay in their SGPRs): node_eval derives some twenty
+// wave-uniform products from them (1/dz, vd Dz / dz^2, (1 - vd) nu_f, P0 / R ...).  Left alone, the compiler hoists these out of
+// the step loop - they are loop-invariant - into VGPRs it does not have: they went to scratch and were reloaded in every
+// residual (9 loads per Newton iteration).  Recomputed per evaluation they cost twenty multiplies and one division beside
+// ~800 instructions.
+__device__ __forceinline__ void opaque_params(const double *p, double (&q)[18]) {
+    SMC_UNROLL
+    for (int i = 0; i < 18; ++i) {
+        q[i] = wave_uniform(p[i]);      // (already scalar in the kernels: they load the parameters through wave_uniform)
+        asm volatile("" : "+s"(q[i]));
+    }
+}
 // wave 0 -> wave 1: the next thing to do.  Every lane stores the same words (no lane branch in front of the barrier); the
 // barrier publishes them together with whatever wave 0 wrote for the command (right-hand side, parameters, differences).
-__device__ __forceinline__ void split_command(double *lds, int cmd, double c, int order) {
-    double *slot = lds + kLdsCmd;
-    slot[0] = (double)cmd;
-    slot[1] = c;
-    slot[2] = (double)order;
+__device__ __forceinline__ void split_command(double *lds, int cmd) {
+    lds[kLdsCmd] = (double)cmd;
     split_barrier();
 }
 
@@ -258,29 +266,37 @@ struct SplitBackward {
     }
 };
 
-// Iteration matrix at the predictor, transposition into the element layout, the wave's chain, the middle node.  Both waves:
-// wave 0 holds node `lane` (its predictor and psi are the integrator's), wave 1 holds node 25 + lane (lane 0: node 25, only as
-// the neighbour of node 26) with predictor and psi recomputed from the differences array.  evals: the lane evaluates a node and
-// writes its coefficient and staging rows (wave 0: nodes 0 .. 25; its lanes 26 .. 50 run along for nothing).
-__device__ __forceinline__ bool split_build_and_factor(int w, int lane_in, int node, bool evals, double *lds, const double *yp,
-                                                       const double *psi, const double *p, double c, double (&X)[kMid + 1],
-                                                       double (&G)[kMid]) {
-    const double cj = 1.0 / c;
+// Iteration matrix at the predictor, transposition into the element layout, the wave's chain, the middle node.  Wave 0 (lane =
+// node, all 51 of them) evaluates the Jacobian blocks, writes every node's coefficient row and stages the blocks one block ROW
+// per pass; both waves pick the entries of their chain's nodes out of the staging row.  The passes alternate between two staging
+// rows (the right-hand-side row and the solution rows, both idle during a factorisation), so ONE barrier per pass is enough:
+// the row written in pass rho + 2 is the one everybody finished reading before the barrier of pass rho + 1.
+// (Wave 1 evaluating the blocks of its own nodes - from a predictor recomputed out of the differences array - saved these seven
+// barriers but put 276 VGPRs' worth of live values into a 256-register wave: eight of its factors lived in scratch, 7 GB of
+// spill stores per launch, and the Jacobian of half the nodes was issued twice.)
+__device__ __forceinline__ bool split_build_and_factor(int w, int lane_in, double *lds, const double *yp, const double *psi,
+                                                       const double *p_in, double c, double (&X)[kMid + 1], double (&G)[kMid]) {
     const SplitChain C(w, opaque_lane(lane_in));
     const ElemLane &L = C.L;
-    double *cf = lds + kLdsCf, *stage = lds + kLdsB, *xch = lds + kLdsXch, *fac = lds + kLdsFac;
-    {
+    double *cf = lds + kLdsCf, *stage0 = lds + kLdsB, *stage1 = lds + kLdsZ, *xch = lds + kLdsXch, *fac = lds + kLdsFac;
+    static_assert(kNX * kZRow >= kNX * 7, "the solution rows hold a staging row");
+    SMC_UNROLL
+    for (int i = 0; i <= kMid; ++i) X[i] = 0.0;
+    if (w == 0) {
+        const double cj = 1.0 / c;
+        const int lane = L.lane;
+        const bool node = lane < kNX;
+        double p[18];
+        opaque_params(p_in, p);
         double wm[7], wp[7], yd0[7], res[7], Lb[kNB], Db[kNB], Ub[kNB];
         neighbours(yp, wm, wp);
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) yd0[f] = psi[f] * cj;
         SMC_UNROLL
         for (int q = 0; q < kNB; ++q) Lb[q] = Db[q] = Ub[q] = 0.0;
-        if (evals) node_eval<true>(node, wm, yp, wp, yd0, p, cj, res, Lb, Db, Ub);
-        SMC_UNROLL
-        for (int i = 0; i <= kMid; ++i) X[i] = 0.0;
-        if (evals) {
-            double *o = cf + node * kCfRow;
+        if (node) {
+            node_eval<true>(lane, wm, yp, wp, yd0, p, cj, res, Lb, Db, Ub);
+            double *o = cf + lane * kCfRow;
             SMC_UNROLL
             for (int r = 0; r < 7; ++r) {
                 o[r] = Lb[r * 7 + r];
@@ -292,20 +308,31 @@ __device__ __forceinline__ bool split_build_and_factor(int w, int lane_in, int n
             o[23] = Ub[6 * 7 + 5];
         }
         SMC_UNROLL
-        for (int rho = 0; rho < 7; ++rho) {   // one block row of the wave's nodes per pass through its part of the staging row
-            if (evals)
+        for (int rho = 0; rho < 7; ++rho) {
+            double *stage = (rho & 1) ? stage1 : stage0;
+            if (node)
                 SMC_UNROLL
-                for (int cc = 0; cc < 7; ++cc) stage[node * 7 + cc] = Db[rho * 7 + cc];
-            wave_lds_sync();
+                for (int cc = 0; cc < 7; ++cc) stage[lane * 7 + cc] = Db[rho * 7 + cc];
+            split_barrier();
             if (L.r == rho && L.c < 7)        // even positions: lane (r, c) holds [r][c]
                 SMC_UNROLL
-                for (int k = 0; k < kMid; k += 2) X[k] = stage[C.node(k) * 7 + L.c];
-            if (L.c == rho && L.r < 7) {      // odd positions (and the odd middle node, wave 0): lane (r, c) holds [c][r]
+                for (int k = 0; k < kMid; k += 2) X[k] = stage[k * 7 + L.c];
+            if (L.c == rho && L.r < 7) {      // odd positions and the odd middle node: lane (r, c) holds [c][r]
                 SMC_UNROLL
-                for (int k = 1; k < kMid; k += 2) X[k] = stage[C.node(k) * 7 + L.r];
-                if (w == 0) X[kMid] = stage[kMid * 7 + L.r];
+                for (int k = 1; k <= kMid; k += 2) X[k] = stage[k * 7 + L.r];
             }
-            wave_lds_sync();
+        }
+    } else {
+        SMC_UNROLL
+        for (int rho = 0; rho < 7; ++rho) {
+            const double *stage = (rho & 1) ? stage1 : stage0;
+            split_barrier();
+            if (L.r == rho && L.c < 7)
+                SMC_UNROLL
+                for (int k = 0; k < kMid; k += 2) X[k] = stage[(kNX - 1 - k) * 7 + L.c];
+            if (L.c == rho && L.r < 7)
+                SMC_UNROLL
+                for (int k = 1; k < kMid; k += 2) X[k] = stage[(kNX - 1 - k) * 7 + L.r];
         }
     }
     int ok = SplitFactorLoop<kMid - 1>::run(C, cf, X, G);
@@ -361,10 +388,12 @@ __device__ __forceinline__ void split_solve(int w, int lane_in, double *lds, con
 
 // one modified-Newton iteration (wave 0); returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
 __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, double *y, double *dd, const double *psi,
-                                                         const double *p, double c, double rtol, double atol,
+                                                         const double *p_in, double c, double rtol, double atol,
                                                          const double (&X)[kMid + 1], const double (&G)[kMid]) {
     const double cj = 1.0 / c;
     const bool node = lane < kNX;
+    double p[18];
+    opaque_params(p_in, p);
     double *b = lds + kLdsB, *z = lds + kLdsZ;
     int finite = 1;
     {
@@ -382,7 +411,7 @@ __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, 
         }
     }
     if (!__all(finite)) return -1.0;     // (no command: wave 1 stays at its barrier)
-    split_command(lds, kCmdSolve, c, 0);
+    split_command(lds, kCmdSolve);
     split_solve(0, lane, lds, X, G);
     double sumsq = 0.0;
     if (node)
@@ -403,37 +432,13 @@ __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, 
 // between commands and nothing else.
 __device__ __forceinline__ void dae_split_server(double *lds, int lane) {
     double X[kMid + 1], G[kMid];
-    const double *slot = lds + kLdsCmd, *par = lds + kLdsPar;
+    const double *slot = lds + kLdsCmd;
     for (;;) {
         split_barrier();
         const int cmd = __builtin_amdgcn_readfirstlane((int)slot[0]);
         if (cmd == kCmdQuit) break;
         if (cmd == kCmdFactor) {
-            const double c = wave_uniform(slot[1]);
-            const int order = __builtin_amdgcn_readfirstlane((int)slot[2]);
-            double p[18];
-            SMC_UNROLL
-            for (int q = 0; q < 18; ++q) p[q] = wave_uniform(par[q]);
-            // predictor and psi of node 25 + lane from the differences array, as the integrator forms them (bdf.py:328-333)
-            const int node = kMid + lane;
-            const bool has = lane <= kNX - 1 - kMid;
-            const DViewE D{lds + kLdsD, has ? node : kMid};
-            double yp[7], psi[7], q7[7];
-            SMC_UNROLL
-            for (int f = 0; f < 7; ++f) yp[f] = q7[f] = 0.0;
-            SMC_UNROLL
-            for (int kk = 0; kk <= kMaxOrder; ++kk)
-                if (kk <= order)
-                    SMC_UNROLL
-                    for (int f = 0; f < 7; ++f) {
-                        const double dv = D(kk, f);
-                        yp[f] += dv;
-                        if (kk >= 1) q7[f] += dv * bdf_gamma(kk);
-                    }
-            const double inv_alpha = 1.0 / bdf_alpha(order);
-            SMC_UNROLL
-            for (int f = 0; f < 7; ++f) psi[f] = q7[f] * inv_alpha;
-            (void)split_build_and_factor(1, lane, node, has && lane >= 1, lds, yp, psi, p, c, X, G);
+            (void)split_build_and_factor(1, lane, lds, nullptr, nullptr, nullptr, 0.0, X, G);
         } else {
             split_solve(1, lane, lds, X, G);
         }
@@ -505,8 +510,8 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
         const bool fresh = !lu_valid || c != c_lu || force_rebuild;
         if (fresh) {
             ++st.nlu;
-            split_command(lds, kCmdFactor, c, order);
-            lu_valid = split_build_and_factor(0, lane, lane, lane < kCut, lds, y, psi, p, c, X, G);      // y is the predictor here
+            split_command(lds, kCmdFactor);
+            lu_valid = split_build_and_factor(0, lane, lds, y, psi, p, c, X, G);      // y is the predictor here
             c_lu = c;
             force_rebuild = false;
         }

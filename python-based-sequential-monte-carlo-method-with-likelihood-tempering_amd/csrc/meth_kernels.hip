@@ -215,8 +215,7 @@ dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y
         if (sidx >= n_solves) break;
         double p[18];
         for (int q = 0; q < 18; ++q) {
-            p[q] = p0_all[sidx * 18 + q];
-            lds[kLdsPar + q] = p[q];
+            p[q] = wave_uniform(p0_all[sidx * 18 + q]);
         }
         if (lane < kNX)
             for (int f = 0; f < 7; ++f) {
@@ -245,7 +244,7 @@ dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y
         if (lane == 0) atomicAdd(&counters[6], 1ULL);   // finished solves
         __builtin_amdgcn_wave_barrier();
     }
-    split_command(lds, kCmdQuit, 0.0, 0);
+    split_command(lds, kCmdQuit);
     if (split && lane == 0) atomicAdd(&counters[7], 1ULL);
 }
 

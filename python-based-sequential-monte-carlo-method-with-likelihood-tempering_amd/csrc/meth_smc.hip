@@ -255,14 +255,13 @@ meth_particles_dae_split_kernel(MethModel m, const double *__restrict__ theta, i
             }
         }
         double p[18];
-        for (int q = 0; q < 10; ++q) p[q] = m.cond[e * 10 + q];
+        for (int q = 0; q < 10; ++q) p[q] = wave_uniform(m.cond[e * 10 + q]);
         for (int jj = 0; jj < 8; ++jj) {  // p_pred_bases[:, est_position] = particle (methanation_functions.py:80)
             double v = m.base[jj];
             for (int kq = 0; kq < m.dim; ++kq)
                 if (m.est_pos[kq] == jj) v = theta[kq * stride + particle];
-            p[10 + jj] = v;
+            p[10 + jj] = wave_uniform(v);
         }
-        for (int q = 0; q < 18; ++q) lds[kLdsPar + q] = p[q];      // for wave 1's Jacobian blocks (published by the first command)
         if (lane < kNX)
             for (int f = 0; f < 7; ++f) {
                 D(0, f) = m.guess[(int64_t)e * kNS + f * kNX + lane];
@@ -290,7 +289,7 @@ meth_particles_dae_split_kernel(MethModel m, const double *__restrict__ theta, i
         }
         __builtin_amdgcn_wave_barrier();
     }
-    split_command(lds, kCmdQuit, 0.0, 0);
+    split_command(lds, kCmdQuit);
     if (split && lane == 0) atomicAdd(&counters->wave_split, 1ULL);
 }
 
