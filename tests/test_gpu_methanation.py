@@ -164,6 +164,41 @@ def _meth_settings(pkg, M, n):
     return pkg.SMCSettings(n_particle=n, priors=priors, seed=20250205), pos
 
 
+def test_two_wave_kernel_equals_the_one_wave_kernel_bit_for_bit(pkg, M, cond_guess, monkeypatch):
+    """K8 v4 (csrc/meth_dae_split.h: integrator wave + chain-server wave per solve, the default) against K8 v3 (one wave per
+    solve, SMC_K8_SPLIT=0).  The split changes who computes what and when, not one floating-point operation: states, flows,
+    status and every counter of 16 prior-box parameter vectors x 30 experiments - some of them failing solves that run
+    their whole attempt budget - must be IDENTICAL; so must a likelihood sweep through the resident path."""
+    cond, guess = cond_guess
+    lo, hi, pos = M.prior_box()
+    rs = np.random.RandomState(11)
+    prs = np.tile(M.BASEPARAMS, (16, 1))
+    prs[:, :4] = (lo[pos] + (hi[pos] - lo[pos]) * rs.uniform(0, 1, (16, 5)))[:, :4]
+    p0 = np.array([M.p0_tuple(cond, i, pr) for pr in prs for i in range(30)])
+    y0 = np.array([guess[i] for pr in prs for i in range(30)])
+    out = {}
+    obs = None
+    for split in ("1", "0"):
+        monkeypatch.setenv("SMC_K8_SPLIT", split)      # read by the library at every launch
+        flows, status, states, info = pkg.methanation.dae_solve_batch(p0, y0, want_states=True)
+        info.pop("kernel_ms")
+        if obs is None:      # observations: the flows of the base parameters (any fixed 5 x 30 table would do)
+            base = np.array([M.p0_tuple(cond, i, M.BASEPARAMS) for i in range(30)])
+            obs = pkg.methanation.dae_solve_batch(base, np.array([guess[i] for i in range(30)]))[0].T.copy()
+        eng, s = _meth_engine(pkg, M, cond, guess, obs, 16)
+        with eng:
+            theta = lo[pos] + (hi[pos] - lo[pos]) * np.random.RandomState(12).uniform(0, 1, (16, 5))
+            eng.upload_particles(pkg.SMC_SET_PRED, theta)
+            eng.loglik(pkg.SMC_SET_PRED)
+            lk = eng.download_lk(pkg.SMC_SET_PRED)
+        out[split] = (flows, status, states, info, lk)
+    a, b = out["1"], out["0"]
+    assert (a[1] != 0).sum() == (b[1] != 0).sum() and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2], equal_nan=True)
+    assert a[3] == b[3] and a[3]["steps"] > 150 * len(p0)
+    assert np.array_equal(a[4], b[4], equal_nan=True) and np.isfinite(a[4]).sum() >= 8
+
+
 def _meth_engine(pkg, M, cond, guess, obs, n):
     s, pos = _meth_settings(pkg, M, n)
     eng = pkg.HipEngine(n, 5, device=0)
