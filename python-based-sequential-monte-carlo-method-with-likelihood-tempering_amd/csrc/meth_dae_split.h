@@ -64,8 +64,8 @@ __device__ __forceinline__ int opaque_lane(int lane) {
 // Which of the workgroup's two waves is the integrator ("main", role 0) and which the chain server (role 1).  The main wave
 // executes vector instructions about half of the time, the server a quarter, so every SIMD should hold one of each.  The
 // dispatcher already sees to that: with four 2-wave workgroups per CU the waves (0, 1) of the groups land on SIMDs (0, 2), (2, 1),
-// (1, 3), (3, 0) - one wave 0 and one wave 1 per SIMD on all 1024 SIMDs (census: SMC_K8_SPLIT_ROLES=4, one printf line per wave,
-// profiles/r04_k8_split_placement.txt) - so policy 0 (wave 0 integrates) is the default.  Policy 1 flips the roles with the
+// (1, 3), (3, 0) - one wave 0 and one wave 1 per SIMD on all 1024 SIMDs (census: a -DSMC_K8_CENSUS build with SMC_K8_SPLIT_ROLES=4, one printf line per
+// wave, profiles/r04_k8_split_placement.txt) - so policy 0 (wave 0 integrates) is the default.  Policy 1 flips the roles with the
 // parity of wave 0's hardware slot (HW_REG_HW_ID bits 3:0); measured: it unbalances half of the SIMDs and is 1 - 2 % slower.
 __device__ __forceinline__ int split_role(double *lds, int wave_in_group, int policy) {
     const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID, bits 3:0 = WAVE_ID
@@ -73,11 +73,13 @@ __device__ __forceinline__ int split_role(double *lds, int wave_in_group, int po
     split_barrier();
     const int slot0 = __builtin_amdgcn_readfirstlane((int)lds[kLdsCmd + 3]);
     const int role = wave_in_group ^ ((policy & 1) ? (slot0 & 1) : 0);
+#ifdef SMC_K8_CENSUS   // census builds only (tools/k8_split_census.sh): a device printf brings loops with divergent exits into the kernel
     if ((policy & 4) && (threadIdx.x & 63) == 0) {   // placement census (SMC_K8_SPLIT_ROLES=4 / 5): one line per wave
         const unsigned hwid = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4), xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
         printf("[k8 placement] group %u wave %d role %d xcc %u se %u cu %u simd %u slot %u\n", blockIdx.x, wave_in_group, role, xcc,
                (hwid >> 13) & 7, (hwid >> 8) & 15, (hwid >> 4) & 3, hwid & 15);
     }
+#endif
     return role;
 }
 // The solve's parameters as values the compiler cannot see through (they stay in their SGPRs): node_eval derives some twenty
@@ -275,7 +277,9 @@ struct SplitBackward {
 // barriers but put 276 VGPRs' worth of live values into a 256-register wave: eight of its factors lived in scratch, 7 GB of
 // spill stores per launch, and the Jacobian of half the nodes was issued twice.)
 __device__ __forceinline__ bool split_build_and_factor(int w, int lane_in, double *lds, const double *yp, const double *psi,
-                                                       const double *p_in, double c, double (&X)[kMid + 1], double (&G)[kMid]) {
+                                                       const double *p_in, double c, double (&X)[kMid + 1], double (&G)[kMid],
+                                                       DaeStats &st) {
+    SMC_PROF_BEGIN();
     const SplitChain C(w, opaque_lane(lane_in));
     const ElemLane &L = C.L;
     double *cf = lds + kLdsCf, *stage0 = lds + kLdsB, *stage1 = lds + kLdsZ, *xch = lds + kLdsXch, *fac = lds + kLdsFac;
@@ -335,8 +339,10 @@ __device__ __forceinline__ bool split_build_and_factor(int w, int lane_in, doubl
                 for (int k = 1; k < kMid; k += 2) X[k] = stage[(kNX - 1 - k) * 7 + L.r];
         }
     }
+    SMC_PROF_ADD(st, 7);   // Jacobian blocks + transposition (wave 0)
     int ok = SplitFactorLoop<kMid - 1>::run(C, cf, X, G);
     ok = __all(ok);
+    SMC_PROF_ADD(st, 0);   // the wave's chain
     if (w) {
         xch[L.lane] = G[kMid - 1];       // H_26
         fac[1] = (double)ok;             // (every lane the same word)
@@ -349,6 +355,7 @@ __device__ __forceinline__ bool split_build_and_factor(int w, int lane_in, doubl
         fac[0] = (double)ok;
     }
     split_barrier();                     // F2
+    SMC_PROF_ADD(st, 3);   // waiting for the other chain + the middle node
     if (w) X[kMid] = xch[L.lane];
     return __builtin_amdgcn_readfirstlane((int)(fac[0] != 0.0)) != 0;
 }
@@ -389,7 +396,8 @@ __device__ __forceinline__ void split_solve(int w, int lane_in, double *lds, con
 // one modified-Newton iteration (wave 0); returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
 __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, double *y, double *dd, const double *psi,
                                                          const double *p_in, double c, double rtol, double atol,
-                                                         const double (&X)[kMid + 1], const double (&G)[kMid]) {
+                                                         const double (&X)[kMid + 1], const double (&G)[kMid], DaeStats &st) {
+    SMC_PROF_BEGIN();
     const double cj = 1.0 / c;
     const bool node = lane < kNX;
     double p[18];
@@ -411,8 +419,10 @@ __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, 
         }
     }
     if (!__all(finite)) return -1.0;     // (no command: wave 1 stays at its barrier)
+    SMC_PROF_ADD(st, 1);   // residual
     split_command(lds, kCmdSolve);
     split_solve(0, lane, lds, X, G);
+    SMC_PROF_ADD(st, 2);   // command + both scans + their barriers
     double sumsq = 0.0;
     if (node)
         SMC_UNROLL
@@ -425,7 +435,9 @@ __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, 
             dd[f] += dx;
         }
     wave_lds_sync();
-    return sqrt(allsum_wave(sumsq) / kNS);
+    const double nrm = sqrt(allsum_wave(sumsq) / kNS);
+    SMC_PROF_ADD(st, 11);  // update + norm
+    return nrm;
 }
 
 // Wave 1: serves the commands of wave 0 until it is told to quit (the kernel is over).  It keeps the factors of its chain
@@ -438,7 +450,8 @@ __device__ __forceinline__ void dae_split_server(double *lds, int lane) {
         const int cmd = __builtin_amdgcn_readfirstlane((int)slot[0]);
         if (cmd == kCmdQuit) break;
         if (cmd == kCmdFactor) {
-            (void)split_build_and_factor(1, lane, lds, nullptr, nullptr, nullptr, 0.0, X, G);
+            DaeStats unused;
+            (void)split_build_and_factor(1, lane, lds, nullptr, nullptr, nullptr, 0.0, X, G, unused);
         } else {
             split_solve(1, lane, lds, X, G);
         }
@@ -455,6 +468,10 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
     const DViewE D{lds + kLdsD, lane};
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
     st.status = 0;
+#ifdef SMC_METH_PROFILE
+    for (int q = 0; q < 12; ++q) st.prof[q] = 0;
+    const long long prof_start_ = clock64();
+#endif
     double t = 0.0, h_abs = h0;
     int order = 1, n_equal = 0, attempts = 0;
     double X[kMid + 1], G[kMid];
@@ -476,7 +493,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
         double t_new = t + h_abs;
         if (t_new - tf > 0) {
             t_new = tf;
-            elem_change_D(D, order, fabs(t_new - t) / h_abs, node);
+            { SMC_PROF_BEGIN(); elem_change_D(D, order, fabs(t_new - t) / h_abs, node); SMC_PROF_ADD(st, 5); }
             n_equal = 0;
         }
         t_new = wave_uniform(t_new);
@@ -484,6 +501,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
         const double h = t_new - t;
         h_abs = fabs(h);
         const double c = h / bdf_alpha(order);
+        SMC_PROF_BEGIN();
         {
             double s[7], q[7];
             SMC_UNROLL
@@ -508,10 +526,11 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
             }
         }
         const bool fresh = !lu_valid || c != c_lu || force_rebuild;
+        SMC_PROF_ADD(st, 6);   // predictor
         if (fresh) {
             ++st.nlu;
             split_command(lds, kCmdFactor);
-            lu_valid = split_build_and_factor(0, lane, lds, y, psi, p, c, X, G);      // y is the predictor here
+            lu_valid = split_build_and_factor(0, lane, lds, y, psi, p, c, X, G, st);      // y is the predictor here
             c_lu = c;
             force_rebuild = false;
         }
@@ -521,7 +540,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
             double dy_norm_old = -1.0;
 #pragma unroll 1
             for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
-                const double dy_norm = split_newton_iteration(lane, lds, y, dd, psi, p, c, rtol, atol, X, G);
+                const double dy_norm = split_newton_iteration(lane, lds, y, dd, psi, p, c, rtol, atol, X, G, st);
                 n_iter = kk + 1;
                 ++st.newton_iters;
                 if (dy_norm < 0) break;
@@ -532,6 +551,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
                 dy_norm_old = dy_norm;
             }
         }
+        SMC_PROF_ADD(st, 8);   // factorisation + Newton loop incl. control
         if (!converged && !fresh) {   // stale matrix: same step again with a fresh one
             force_rebuild = true;
             continue;
@@ -540,7 +560,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
             ++st.newton_fail;
             lu_valid = false;
             h_abs *= 0.5;
-            elem_change_D(D, order, 0.5, node);
+            { SMC_PROF_BEGIN(); elem_change_D(D, order, 0.5, node); SMC_PROF_ADD(st, 5); }
             n_equal = 0;
             continue;
         }
@@ -558,10 +578,11 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
             ++st.rejects;
             const double factor = (error_norm == error_norm) ? fmax(0.2, safety * pow(error_norm, -1.0 / (order + 1))) : 0.2;
             h_abs *= factor;
-            elem_change_D(D, order, factor, node);
+            { SMC_PROF_BEGIN(); elem_change_D(D, order, factor, node); SMC_PROF_ADD(st, 5); }
             n_equal = 0;
             continue;
         }
+        SMC_PROF_ADD(st, 9);   // error test
         ++n_equal;
         t = t_new;
         ++st.steps;
@@ -594,6 +615,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
                     if (order < kMaxOrder) { const double e = bdf_error_const(order + 1) * dnew2[f] * isc; sp += e * e; }
                 }
         }
+        SMC_PROF_ADD(st, 10);  // D update + order-selection norms
         if (!select) continue;
         const double inf = __longlong_as_double(0x7ff0000000000000LL);
         const double em_s = sqrt(allsum_wave(sm) / (6 * kNX)), ep_s = sqrt(allsum_wave(sp) / (6 * kNX));
@@ -607,10 +629,13 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
         order += delta;
         const double factor = fmin(10.0, safety * best);
         h_abs *= factor;
-        elem_change_D(D, order, factor, node);
+        { SMC_PROF_BEGIN(); elem_change_D(D, order, factor, node); SMC_PROF_ADD(st, 5); }
         n_equal = 0;
     }
     st.status = __builtin_amdgcn_readfirstlane(st.status);
+#ifdef SMC_METH_PROFILE
+    st.prof[4] = clock64() - prof_start_;
+#endif
 }
 
 }  // namespace meth

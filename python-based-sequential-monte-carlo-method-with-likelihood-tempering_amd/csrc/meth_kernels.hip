@@ -238,6 +238,10 @@ dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y
             atomicAdd(&counters[1], (unsigned long long)st.rejects);
             atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
+#ifdef SMC_METH_PROFILE
+            atomicAdd(&counters[4], (unsigned long long)st.nlu);
+            for (int q = 0; q < 12; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
+#endif
         }
         if (y_final && lane < kNX)
             for (int f = 0; f < 7; ++f) y_final[sidx * kNS + f * kNX + lane] = D(0, f);
@@ -419,10 +423,10 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
     {
         unsigned long long h[24];
         MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
-        static const char *nm[12] = {"build+factor", "residual", "forward", "backward", "total", "change_D", "predictor", "jac+transpose", "factor+newton", "error test", "Dupd+select", "-"};
+        static const char *nm[12] = {"build+factor", "residual", "forward", "backward", "total", "change_D", "predictor", "jac+transpose", "factor+newton", "error test", "Dupd+select", "update+norm"};   // v4: "build+factor" = the wave's chain, "forward" = command + both scans, "backward" = wait + middle node
         fprintf(stderr, "[meth profile] solves %lld  nlu/solve %.1f  newton/solve %.1f  steps/solve %.1f\n", (long long)n_solves,
                 (double)h[4] / n_solves, (double)h[3] / n_solves, (double)h[0] / n_solves);
-        for (int q = 0; q < 11; ++q)
+        for (int q = 0; q < 12; ++q)
             fprintf(stderr, "[meth profile] %-14s %10.0f cycles/solve  (%.1f %% of total)\n", nm[q], (double)h[8 + q] / n_solves,
                     100.0 * h[8 + q] / (double)h[12]);
         fprintf(stderr, "[meth profile] per factorisation %.0f cycles; per newton iteration: residual %.0f forward %.0f backward %.0f\n",

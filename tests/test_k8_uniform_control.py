@@ -209,3 +209,37 @@ def test_user_model_kernel_is_under_the_same_control_flow_checks(pkg, tmp_path, 
         loop = [l for l in body[lab:back + 1] if l and not l.startswith(";")]
         assert not [l for l in loop if re.match(r"s_\w+_saveexec", l)], f"{model}: exec-mask control flow in the uniform attempt loop"
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc from ROCm")
+def test_two_wave_k8_kernel_keeps_its_loops_free_of_scratch_stores(tmp_path):
+    """The two-wave K8 kernel (csrc/meth_dae_split.h) is compiled for 256 VGPRs - two waves per SIMD - and lives at that limit.
+    A value the register allocator parks in scratch INSIDE the step loop is stored once per factorisation or per step by every
+    lane: an earlier build wrote 7 GB per launch that way, against 45 MB of algorithmic traffic (profiles/r04_ab_k8_split.log).
+    Checked on the CPU from the listing: scratch stores may only sit outside every loop (the kernel's entry), and the scratch
+    loads inside loops stay few (reloads of hoisted constants)."""
+    asm = str(tmp_path / "k.s")
+    subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", "-o", asm, os.path.join(CSRC, "meth_smc.hip")], check=True,
+                   stderr=subprocess.DEVNULL, timeout=900)
+    lines = open(asm).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3smc31meth_particles_dae_split_kernel\w*:", l))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    in_loop, stores_in_loops, loads_in_loops, stores_outside = False, 0, 0, 0
+    for l in lines[start + 1:end]:
+        m = re.match(r"^\.LBB\d+_\d+:\s*(;.*)?$", l)
+        if m:
+            in_loop = "Loop" in (m.group(1) or "")
+            continue
+        t = l.strip()
+        if t.startswith("scratch_store"):
+            stores_in_loops += in_loop
+            stores_outside += not in_loop
+        elif t.startswith("scratch_load"):
+            loads_in_loops += in_loop
+    meta = "\n".join(lines)
+    k = meta.index(".name:           _ZN3smc31meth_particles_dae_split_kernel")
+    vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", meta[k:]).group(1))
+    assert vgprs <= 256, vgprs                      # two waves per SIMD
+    assert stores_in_loops == 0, f"{stores_in_loops} scratch stores inside loops"
+    assert loads_in_loops <= 48, loads_in_loops     # static count; 25 at the time of writing
+    shutil.rmtree(tmp_path, ignore_errors=True)
