@@ -25,9 +25,10 @@
 // PARITY UNPINNED against the reference's IDA (see meth_dae.h); checked against v2, the CPU build and the CPU checker.
 //
 // Round 4: TWO-ENDED elimination.  K8 is bound by dependent chains at one wave per SIMD (vector ALUs busy 44 % of the cycles,
-// profiles/r04_k8_pmc_sq_summary.json): a scan step waits ~13 cycles for every dependent FP64 operation while the issue slots
-// stay empty, and neither a second wave per SIMD (204 VGPRs of factors, 38.8 KB of LDS per solve) nor the matrix cores (a chained
-// v_mfma_f64_4x4x4 costs 48 cycles) are a way out.  What a single wave CAN do is run two independent chains in one instruction
+// profiles/r04_k8_oneway_pmc_sq_summary.json): a scan step waits ~13 cycles for every dependent FP64 operation while the issue slots
+// stay empty, and neither a second wave per SIMD (204 VGPRs of factors, 38.8 KB of LDS per solve - for THIS kernel: meth_dae_split.h
+// later gives each chain a wave of its own and gets there) nor the matrix cores (a chained v_mfma_f64_4x4x4 costs 48 cycles) are a
+// way out.  What a single wave CAN do is run two independent chains in one instruction
 // stream.  The block-tridiagonal system is therefore eliminated from BOTH ends at once ("twisted" / burn-at-both-ends
 // factorisation): nodes 0 .. 24 downwards as before (D'_i = D_i - L_i G_{i-1},  G_i = D'_i^{-1} U_i), nodes 50 .. 26 upwards
 // (D''_i = D_i - U_i H_{i+1},  H_i = D''_i^{-1} L_i), meeting in node 25 (D*_25 = D_25 - L_25 G_24 - U_25 H_26); the right-hand
