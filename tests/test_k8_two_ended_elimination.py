@@ -150,3 +150,73 @@ def test_off_diagonal_blocks_have_the_structure_the_scans_assume(hc, M):
         assert not np.any(Lb[i][~okL]), i
     for i in range(NX - 1):
         assert not np.any(Ub[i][~okU]), i
+
+
+# ---- K8 v4 (csrc/meth_dae_split.h): ONE chain step for both directions, the direction in the coefficient SLOTS ------------------
+def _split_offsets(w, mr, mc):
+    """SplitOffsets as csrc/meth_dae_split.h:split_offsets computes them (checked against the header's text below): slots of a
+    node's coefficient row [0..6] ld, [7] 0, [8..14] lx, [15] 0, [16..21] ud, [22] 0, [23] u65."""
+    r6, c6 = min(mr, 6), min(mc, 6)
+    if w == 0:
+        return dict(f1=r6, f2=8 + r6, gd=16 + c6, ge=23, s1=c6, s2=(8 + mc) if mc < 6 else 7, s3=7 if mc < 6 else 14)
+    return dict(f1=16 + r6, f2=23 if mr == 6 else 7, gd=c6, ge=14, s1=16 + c6, s2=7, s3=22 if mc < 6 else 23)
+
+
+def _cf_row(Lb, Ub):
+    row = np.zeros(25)
+    for r in range(7):
+        row[r] = Lb[r, r]
+        row[8 + r] = Lb[r, 6] if r < 6 else Lb[6, 5]
+        row[16 + r] = Ub[r, r] if r < 6 else 0.0
+    row[23] = Ub[6, 5]
+    return row
+
+
+def _sparse_blocks(rs):
+    Lb, Ub = np.zeros((7, 7)), np.zeros((7, 7))
+    Lb[np.arange(7), np.arange(7)] = rs.standard_normal(7)
+    Lb[:6, 6] = rs.standard_normal(6)
+    Lb[6, 5] = rs.standard_normal()
+    Ub[np.arange(6), np.arange(6)] = rs.standard_normal(6)
+    Ub[6, 5] = rs.standard_normal()
+    return Lb, Ub
+
+
+def test_the_header_still_holds_the_slot_table_this_test_restates():
+    txt = open(os.path.join(ROOT, "python-based-sequential-monte-carlo-method-with-likelihood-tempering_amd", "csrc",
+                            "meth_dae_split.h")).read()
+    body = txt[txt.index("__device__ __forceinline__ SplitOffsets split_offsets("):txt.index("struct SplitChain {")]
+    flat = " ".join(body.split())
+    for piece in ("o.f1 = r6;", "o.f2 = 8 + r6;", "o.gd = 16 + c6;", "o.ge = 23;", "o.s1 = c6;", "o.s2 = (mc < 6) ? 8 + mc : 7;",
+                  "o.s3 = (mc < 6) ? 7 : 8 + 6;", "o.f1 = 16 + r6;", "o.f2 = (mr == 6) ? 23 : 7;", "o.gd = c6;", "o.ge = 8 + 6;",
+                  "o.s1 = 16 + c6;", "o.s2 = 7;", "o.s3 = (mc < 6) ? 22 : 23;"):
+        assert piece in flat, piece
+
+
+def test_one_chain_step_serves_both_directions_through_its_coefficient_slots():
+    """Downwards the elimination couples through L_i G_{i-1} and forms G_i = X_i U_i, upwards through U_i H_{i+1} and H_i = X_i L_i;
+    the right-hand side meets L_i z_{i-1} resp. U_i w_{i+1}.  K8 v4 runs ONE instruction stream for both:
+        coupling      (C g)[mr][mc]  = cf[f1] g[mr][mc] + cf[f2] g[mr < 6 ? 6 : 5][mc]
+        factor        (X C')[mr][mc] = X[mr][mc] cf[gd] + (mc == 5) X[mr][6] cf[ge]  (+ upwards, mc == 6: sum_{k<6} X[mr][k] lx[k])
+        right side    (C z)[mc]      = cf[s1] z[mc] + cf[s2] z[6] + cf[s3] z[5]
+    with the slots of `split_offsets` - checked here against the dense products for random blocks of the structure the product's
+    Jacobian has (test above)."""
+    rs = np.random.RandomState(5)
+    for _ in range(20):
+        Lb, Ub = _sparse_blocks(rs)
+        cf = _cf_row(Lb, Ub)
+        g, X, z = rs.standard_normal((7, 7)), rs.standard_normal((7, 7)), rs.standard_normal(7)
+        for w, C, Cp in ((0, Lb, Ub), (1, Ub, Lb)):
+            want_couple, want_factor, want_rhs = C @ g, X @ Cp, C @ z
+            for mr in range(7):
+                for mc in range(7):
+                    o = _split_offsets(w, mr, mc)
+                    kap = 6 if mr < 6 else 5
+                    assert np.isclose(cf[o["f1"]] * g[mr, mc] + cf[o["f2"]] * g[kap, mc], want_couple[mr, mc], rtol=1e-13, atol=1e-13)
+                    fac = X[mr, mc] * cf[o["gd"]] + (X[mr, 6] * cf[o["ge"]] if mc == 5 else 0.0)
+                    if w == 1 and mc == 6:
+                        fac = X[mr, mc] * cf[o["gd"]] + sum(X[mr, k] * cf[8 + k] for k in range(6))
+                    assert np.isclose(fac, want_factor[mr, mc], rtol=1e-13, atol=1e-13)
+            for mc in range(7):
+                o = _split_offsets(w, 0, mc)
+                assert np.isclose(cf[o["s1"]] * z[mc] + cf[o["s2"]] * z[6] + cf[o["s3"]] * z[5], want_rhs[mc], rtol=1e-13, atol=1e-13)
