@@ -307,6 +307,40 @@ class init_watchdog:
         self.t.cancel()
 
 
+RUN_STALL_TIMEOUT_S = float(os.environ.get("SMC_BENCH_RUN_TIMEOUT", "300"))
+
+
+class run_watchdog:
+    """N > 1 only: every rank must finish a complete run (73 ms of work at the default size) within RUN_STALL_TIMEOUT_S of the
+    previous one.  Ranks that disagree on a collective - which the matched-by-construction all-reduces of a speculative batch
+    and the planned exchange of a resampling step must never do, and which no test on real GPUs has exercised yet - would wait
+    inside RCCL for ever; this rank then reports where it stood and leaves with status 5, and the launcher ends the others."""
+
+    def __init__(self, rank, world):
+        import threading
+        self.rank, self.world, self.last, self.what = rank, world, time.monotonic(), "start"
+        self.stop = threading.Event()
+        self.t = threading.Thread(target=self._watch, daemon=True)
+
+    def beat(self, what):
+        self.last, self.what = time.monotonic(), what
+
+    def _watch(self):
+        while not self.stop.wait(1.0):
+            if time.monotonic() - self.last > RUN_STALL_TIMEOUT_S:
+                print(f"bench.py: rank {self.rank} of {self.world} made no progress for {RUN_STALL_TIMEOUT_S:.0f} s after '{self.what}'; leaving",
+                      file=sys.stderr, flush=True)
+                os._exit(5)
+
+    def __enter__(self):
+        if self.world > 1:
+            self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+
+
 def make_comm(pkg, eng, rank, world):
     """SingleComm, or the engine's RCCL communicator."""
     if world == 1:
@@ -612,24 +646,27 @@ def main():
     def one_run(i):
         return pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=1000 + i)
 
-    for i in range(args.warmup):
-        one_run(-1 - i)
-    eng.timing_enable(True)
-    eng.timing_reset()
-    comm.barrier()
-    eng.synchronize()
-    t0 = time.perf_counter()
-    outs = []
-    for i in range(args.steps):
-        out = one_run(i)
-        if outs:                      # only the last run's particles are looked at below: let the earlier result arrays go (their
-            outs[-1].pop("p_pred")    # page-locked buffers return to the pool and serve the next run's download)
-            outs[-1].pop("lk")
-        outs.append(out)
-    comm.barrier()
-    eng.synchronize()
-    elapsed = time.perf_counter() - t0
-    per_rank_s = np.asarray(comm.allgather([elapsed]), dtype=np.float64).reshape(-1)      # every rank's own clock
+    with run_watchdog(rank, world) as dog:
+        for i in range(args.warmup):
+            one_run(-1 - i)
+            dog.beat(f"warm-up run {i}")
+        eng.timing_enable(True)
+        eng.timing_reset()
+        comm.barrier()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        outs = []
+        for i in range(args.steps):
+            out = one_run(i)
+            dog.beat(f"timed run {i}")
+            if outs:                      # only the last run's particles are looked at below: let the earlier result arrays go (their
+                outs[-1].pop("p_pred")    # page-locked buffers return to the pool and serve the next run's download)
+                outs[-1].pop("lk")
+            outs.append(out)
+        comm.barrier()
+        eng.synchronize()
+        elapsed = time.perf_counter() - t0
+        per_rank_s = np.asarray(comm.allgather([elapsed]), dtype=np.float64).reshape(-1)      # every rank's own clock
     elapsed = float(per_rank_s.max())
     rccl = eng.comm_info() if world > 1 else {"count": 0, "user_rank": -1, "device": -1}
     timing = eng.timing_get()

@@ -146,3 +146,21 @@ def test_kernel_revision_hash_ignores_comments(tmp_path):
     assert bench.kernel_source_sha(str(tmp_path)) == a
     f.write_text(f.read_text().replace("#define A21 (1.0 / 5)", "#define A21 (1.0 / 4)"))
     assert bench.kernel_source_sha(str(tmp_path)) != a
+
+
+def test_run_watchdog_ends_a_rank_that_stops_making_progress():
+    """N > 1: a rank that waits inside a collective its peers never enter would hang for ever; bench.py's run watchdog reports
+    where the rank stood and leaves with status 5 (rehearsed without a GPU: the class alone, in a child process)."""
+    code = ("import os, sys, time\n"
+            "os.environ['SMC_BENCH_RUN_TIMEOUT'] = '2'\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "import bench\n"
+            "with bench.run_watchdog(1, 2) as dog:\n"
+            "    dog.beat('timed run 3')\n"
+            "    time.sleep(30)\n"
+            "print('not reached')\n")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 5 and "rank 1 of 2 made no progress" in p.stderr and "timed run 3" in p.stderr and "not reached" not in p.stdout
+    code1 = code.replace("run_watchdog(1, 2)", "run_watchdog(0, 1)").replace("time.sleep(30)", "time.sleep(4)")
+    p = subprocess.run([sys.executable, "-c", code1], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "not reached" in p.stdout          # one rank: no watchdog (a long single-GPU run is not a hang)
