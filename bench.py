@@ -44,6 +44,12 @@ HBM_PEAK_GBPS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic FP64 flop of one particle-mutation-step (DESIGN.md "Kernels"):
 FLOP_PER_RK_ATTEMPT = 100        # 6 RHS (3 flop each) + stage sums + y_new + error estimate + controller
 FLOP_PER_PARTICLE_FIXED = 6 * 40 * 14 + 240 * 4 + 6 * 12 + 50   # dense-output points, residuals, logL, accept
+# ... the same fixed term split by who earns it: a (particle, experiment) solve that RAN TO THE END produced 40 dense outputs
+# (14 flop each), 40 residuals (4 each) and one logL term (12); a particle of a sweep that had work is accepted or rejected (50).
+# Cancelled (exact early rejection) and masked (out of support) proposals, and the speculative launches of a batch that find
+# the loop ended, earn nothing
+FLOP_PER_SOLVED_ITEM = 40 * 14 + 40 * 4 + 12
+FLOP_PER_PARTICLE_ACCEPT = 50
 HBM_BYTES_PER_PARTICLE_SOLVE = 24 + 1 + 6 * (8 + 4)  # read theta + support flag; write 6 x (sum_r2, info)
 
 
@@ -73,15 +79,58 @@ def effective_cpus():
     return n
 
 
-def cpu_baseline(sample_seconds_target=15.0):
-    """The reference's per-particle path (SciPy solve_ivp RK45 per particle x experiment, one task per
-    particle on a process pool = the Ray fan-out, Micmem_likelihood.py:83) timed on this box's host
-    cores on a bounded sample of the same workload: one mutation-sweep-equivalent likelihood pass over
-    M posterior-like particles.  The code timed is oracle/oracle.py's NumPy/SciPy counterpart (the
-    reference's files do not travel to this box)."""
+def cpu_stage_times(O):
+    """ESS iteration and resampling loop exactly as the reference writes them (Micmem_SMC_main.py:124-134, :147-184; NumPy
+    passes and a pure-Python loop, one core), at the sizes SURVEY.md 8(d) names."""
+    rs = np.random.RandomState(0)
+    out = {"ess_iteration_s": {}, "ess_iters_per_s": {}, "resample_loop_s": {}}
+    for n in (1_000, 100_000, 1_000_000):
+        lk = -np.abs(rs.standard_normal(n)) * 300
+        d_lk = lk - lk.max()
+        reps = 200 if n == 1_000 else 20 if n == 100_000 else 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            w = np.exp(d_lk * 0.01)               # :124
+            sw = np.sum(w)                        # :126
+            w = w / sw                            # :128
+            ess = 1.0 / np.sum(w ** 2) / n        # :130-134
+        dt = (time.perf_counter() - t0) / reps
+        out["ess_iteration_s"][str(n)] = dt
+        out["ess_iters_per_s"][str(n)] = 1.0 / dt
+        assert 0.0 < ess <= 1.0
+        if n <= 100_000:                          # the pure-Python loop: 2.3 s at 1e6 in the survey container - not repeated here
+            p_pred, p_filt, lk1 = rs.uniform(0, 10, (n, 3)), np.zeros((n, 3)), np.zeros(n)
+            t0 = time.perf_counter()
+            _, n_out, _ = O.resample_python(w, 0.5, p_pred, lk, p_filt, lk1)
+            out["resample_loop_s"][str(n)] = time.perf_counter() - t0
+            assert n_out == n
+    return out
+
+
+def cpu_baseline(sample_seconds_target=4.0):
+    """the NumPy/SciPy counterpart of the reference's driver (oracle.run_smc: the statement sequence of
+    Micmem_SMC_main.py:98-262 on NumPy's global legacy RNG; scipy.solve_ivp RK45 per particle x experiment on a fork pool with
+    one worker per host core = the reference's one Ray task per particle, Micmem_likelihood.py:83; the resampling loop in pure
+    Python as written) run END TO END at N = 1000 on the reference's seed.  Before its time counts the run must reproduce the
+    reference run's schedule (tests/golden/mm_ref_run_n1000.npz: gamma bit for bit, accept counts, loop lengths, final
+    particles).  The reference's own files do not travel to this box: `kind` is "port"."""
     O = entry.load_oracle()
     data = O.MMData.load()
     cores = effective_cpus()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "mm_ref_run_n1000.npz"))
+    t0 = time.perf_counter()
+    out = O.run_smc(data, O.SMCSettings(), seed=int(g["seed"]), loglik="scipy", n_threads=cores, record_mh=False, resample_impl="python")
+    dt_run = time.perf_counter() - t0
+    rec = out["records"]
+    pinned = (out["step"] == int(g["final_step"]) and np.array_equal([r.gamma_new for r in rec], g["sched_gamma"])
+              and np.array_equal([r.n_accept for r in rec], g["sched_accept"]) and np.array_equal([r.last_j for r in rec], g["sched_last_j"])
+              and np.array_equal(out["p_pred"], g["final_p_pred"]))
+    if not pinned:
+        raise RuntimeError("cpu_baseline: the NumPy/SciPy port did not reproduce the reference run's schedule; its time is void")
+    n = 1000
+    pms = out["n_mutation_sweeps"] * n
+    # second figure: one likelihood pass over posterior-like particles (the steady-state regime of `steady_state`), SciPy and the
+    # C restatement of the same arithmetic on all cores
     rs = np.random.RandomState(0)
     per_core_rate = 230.0  # likelihoods/s/core on the GPU box's host CPU (78 in the survey container); sizes the sample only
     m = int(max(cores * 8, min(60000, per_core_rate * cores * sample_seconds_target)))
@@ -89,27 +138,23 @@ def cpu_baseline(sample_seconds_target=15.0):
     t0 = time.perf_counter()
     lk = O.mm_loglik_batch_scipy(theta, data, n_workers=cores)
     dt = time.perf_counter() - t0
-    # C restatement of the same pass on all cores (second, faster CPU figure)
     t1 = time.perf_counter()
     lk_c, _, info = O.mm_loglik_batch(np.tile(theta, (8, 1)), data, n_threads=cores)
     dt_c = time.perf_counter() - t1
     assert np.max(np.abs(lk - lk_c[:m]) / np.maximum(1, np.abs(lk))) < 1e-9
-    # ESS iteration as the reference writes it (Micmem_SMC_main.py:124-134), N = 1e6, one core
-    lk6 = -np.abs(rs.standard_normal(1_000_000)) * 300
-    d_lk = lk6 - lk6.max()
-    t2 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        w = np.exp(d_lk * 0.01)
-        sw = np.sum(w)
-        w = w / sw
-        ess = 1.0 / np.sum(w ** 2) / 1_000_000
-    dt_e = (time.perf_counter() - t2) / reps
-    return {"value": m / dt, "unit": "particle-mutation-steps/s", "cores": cores, "kind": "port",
-            "sample": f"one likelihood pass (the >98% term of a mutation step) over {m} posterior-like particles, "
-                      f"scipy.solve_ivp RK45 x 6 experiments each, fork pool of {cores} workers, {dt:.1f}s",
+    st = cpu_stage_times(O)
+    return {"value": pms / dt_run, "unit": "particle-mutation-steps/s", "cores": cores, "kind": "port",
+            "sample": f"one COMPLETE adaptive-tempering run at N = {n} on the reference's seed (prior -> gamma = 1: {out['step']} tempering "
+                      f"steps, {out['n_mutation_sweeps']} Metropolis sweeps + the initial sweep, {out['n_ess_iters']} ESS iterations), "
+                      f"scipy.solve_ivp RK45 x 6 experiments per particle on a fork pool of {cores} workers, resampling loop in pure "
+                      f"Python, {dt_run:.1f} s; schedule, accept counts and final particles equal the reference run's (asserted first)",
+            "run_s": dt_run, "run_stage_s": out["stage_s"], "schedule_pinned": True,
+            "ess_iters_per_s_in_run": out["n_ess_iters"] / out["stage_s"]["ess_search"],
+            "likelihood_pass": {"value": m / dt, "unit": "particle-mutation-steps/s", "particles": m, "seconds": dt,
+                                "what": "one likelihood pass (the > 98 % term of a mutation step) over posterior-like particles, same pool"},
             "c_restatement_value": 8 * m / dt_c, "c_restatement_cores": cores,
-            "ess_iters_per_s_n1e6_1core": 1.0 / dt_e}
+            "ess_iteration_s": st["ess_iteration_s"], "ess_iters_per_s": st["ess_iters_per_s"], "resample_loop_s": st["resample_loop_s"],
+            "ess_iters_per_s_n1e6_1core": st["ess_iters_per_s"]["1000000"]}
 
 
 def cpu_baseline_methanation(pkg, cond, guess, sample_seconds_target=15.0):
@@ -422,10 +467,18 @@ def bench_methanation(args):
     """Config 4 (BASELINE.json configs[3]): methanation kinetics, 30 experiments per particle, 357-state DAE per
     experiment.  One step = one complete adaptive-tempering SMC run on one GPU.  The reference's inlet table is
     missing upstream: synthetic conditions (tests/golden/methanation_information.csv), observations = model at
-    baseparams + sigma = 5 noise (SMC_methanation_main.py:89-101).  K8 is parity-unpinned (DESIGN.md 4.4)."""
+    baseparams + sigma = 5 noise (SMC_methanation_main.py:89-101).  K8 is parity-unpinned (DESIGN.md 4.5)."""
+    n = args.particles_per_gpu if args.particles_per_gpu != 1_000_000 else 1024
+    line = methanation_line(args, n, args.steps, args.warmup, cpu_seconds=15.0)
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+def methanation_line(args, n, steps, warmup, cpu_seconds):
+    """The methanation workload's whole bench line as a dict (rank 0; None on the other ranks): `--workload methanation` prints
+    it, the default Michaelis-Menten line carries it at N = 1024 under the key `methanation_n1024`."""
     pkg = entry.load_package()
     M = pkg.methanation                          # settings-layer conversions (methanation_set_conditon.py as functions)
-    n = args.particles_per_gpu if args.particles_per_gpu != 1_000_000 else 1024
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))   # config 5: particle-sharded
     cond = M.load_conditions(os.path.join(ROOT, "tests", "golden", "methanation_information.csv"))
     guess = M.initial_guess(cond)
@@ -433,16 +486,19 @@ def bench_methanation(args):
     base = np.append(M.BASEPARAMS, M.SIGMA_TRUE)
     priors = {nm: {"dist": "uniform", "low": float(lo[i]), "high": float(hi[i])}
               for nm, i in zip(["Af", "Eaf", "Ar", "Ear", "sigma"], pos)}
-    s = pkg.SMCSettings(n_particle=n * world, priors=priors)
+    mh_batch = args.mh_batch if args.mh_batch == "auto" else int(args.mh_batch)
+    s = pkg.SMCSettings(n_particle=n * world, priors=priors, mh_batch=mh_batch)
     p0 = M.p0_rows(cond, M.BASEPARAMS)
-    flows0, _, _, _ = pkg.methanation.dae_solve_batch(p0, guess, device=int(os.environ.get("LOCAL_RANK", "0")))   # synthetic data
+    dev = int(os.environ.get("SMC_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    flows0, _, _, _ = pkg.methanation.dae_solve_batch(p0, guess, device=dev)   # synthetic data
     np.random.seed(20250205)
     obs = flows0.T + 5.0 * np.random.standard_normal((5, 30))
-    eng = pkg.HipEngine(n, 5, device=int(os.environ.get("LOCAL_RANK", "0")), n_global=n * world)
+    eng = pkg.HipEngine(n, 5, device=dev, n_global=n * world)
     eng.set_model_methanation(cond, guess, obs, base, pos)
     eng.set_prior(priors)
     if args.meth_sweeps > 0:
-        return bench_methanation_sweeps(args, pkg, eng, s, n)
+        bench_methanation_sweeps(args, pkg, eng, s, n)
+        return None
     comm = make_comm(pkg, eng, rank, world)
     s.early_reject = not args.no_early_reject
     s.stiff_first = not args.no_stiff_first      # methanation: adaptive experiment order of the early-rejection sweeps
@@ -456,25 +512,26 @@ def bench_methanation(args):
 
             def w(*a, **k):
                 out = f(*a, **k)
-                chk = eng.meth_sweep_check()
+                chk = eng.meth_sweep_check()      # of the last sweep that ran
                 line = (f"[{time.perf_counter() - t_begin:8.1f} s] {name}: gamma {a[0] if name != 'loglik' else 0.0:.6g}, "
                         f"{chk['completed_solves']} solved + {chk.get('cancelled_solves', 0)} cancelled of {chk['expected_solves']}"
-                        + (f", accepted {out.get('accepted_now')}" if isinstance(out, dict) and "accepted_now" in out else ""))
+                        + (f", accepted {out.get('accepted_now')}" if isinstance(out, dict) and "accepted_now" in out else "")
+                        + (f", {out['n_done']} iterations" if isinstance(out, dict) and "n_done" in out else ""))
                 print(line, file=sys.stderr, flush=True)
                 prog.write(line + "\n")
                 prog.flush()
                 return out
             setattr(eng, name, w)
-        for nm in ("loglik", "mh_iteration_device_rng"):
+        for nm in ("loglik", "mh_iteration_device_rng", "mh_sweeps_device_rng"):
             wrap(nm)
-    for i in range(args.warmup):
+    for i in range(warmup):
         pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=900 + i)
     eng.timing_enable(True)
     eng.timing_reset()
     comm.barrier()
     eng.synchronize()
     t0 = time.perf_counter()
-    outs = [pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=1000 + i) for i in range(args.steps)]
+    outs = [pkg.run_smc(eng, s, comm=comm, rng="device", verbose=False, seed_device=1000 + i) for i in range(steps)]
     comm.barrier()
     eng.synchronize()
     elapsed = float(comm.allreduce_max([time.perf_counter() - t0])[0])
@@ -482,9 +539,9 @@ def bench_methanation(args):
     if rank != 0:
         comm.barrier()
         eng.close()
-        return
+        return None
     pms = sum(o["stats"]["particle_mutation_steps"] for o in outs)
-    sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs) + args.steps
+    sweeps = sum(o["stats"]["mutation_sweeps"] for o in outs) + steps
     solves = sum(o["stats"].get("dae_solves", 0) for o in outs)                       # device-counted: solves actually done
     cancelled = sum(o["stats"].get("dae_solves_cancelled", 0) for o in outs)          # ... and skipped by exact early rejection
     k8 = {k: sum(o["stats"].get(k, 0) for o in outs) for k in ("bdf_steps", "newton_iters", "factorisations", "failed_solves")}
@@ -492,18 +549,20 @@ def bench_methanation(args):
     # counter traffic of K8 per launch: only from a PMC summary of THIS kernel revision at THIS population (same rule as the MM line)
     traffic, traffic_note = measured_traffic("smc::" + k8_kernel_name(), n, family="k8")
     k8_launches = max(1, tm["solve"]["launches"])
-    cpu = None if (args.no_cpu_baseline or world != 1) else cpu_baseline_methanation(pkg, cond, guess)
-    print(json.dumps({
+    cpu = None if (args.no_cpu_baseline or world != 1 or cpu_seconds <= 0) else cpu_baseline_methanation(pkg, cond, guess, cpu_seconds)
+    line = {
         "metric": "particle-mutation-steps/sec", "value": pms / elapsed, "unit": "particle-mutation-steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "methanation kinetics (30 experiments x 357-state DAE per particle), adaptive tempering, "
                                "reference defaults; one step = one full SMC run; synthetic inlet table and observations",
                    "particles_per_gpu": n, "rng": "device Philox4x32-10", "parity": "K8 unpinned (no IDA in the image)",
-                   "early_reject": bool(s.early_reject)},
+                   "early_reject": bool(s.early_reject), "mh_batch": mh_batch},
         "dae_solves_per_s": solves / (tm["solve"]["ms"] * 1e-3), "dae_solves": solves, "dae_solves_cancelled": cancelled,
         "dae_solves_without_early_rejection": solves + cancelled,
-        "tempering_steps_per_run": [o["step"] for o in outs], "mutation_sweeps": sweeps - args.steps,
+        "per_solve": {k: k8[k] / max(1, solves) for k in ("bdf_steps", "newton_iters", "factorisations")},
+        "mh_loop_synchronisations": sum(o["stats"].get("mh_syncs", 0) for o in outs),
+        "tempering_steps_per_run": [o["step"] for o in outs], "mutation_sweeps": sweeps - steps,
         "posterior_mean": outs[-1]["p_pred"].mean(axis=0).tolist(), "posterior_std": outs[-1]["p_pred"].std(axis=0).tolist(),
         "logZ": [o["logZ"] for o in outs], "kernel_ms": tm,
         "roofline": {"kernel": k8_kernel_name() + " (BDF solve per workgroup: integrator wave + chain-server wave)", "bound": "mfma", "bound_note": "FP64 vector FMAs, latency-bound scans; MFMA unused (7x7 blocks)",
@@ -520,9 +579,10 @@ def bench_methanation(args):
                      "hbm": {"algorithmic_bytes_per_launch": (solves / k8_launches) * (357 * 8 + 10 * 8 + 5 * 8 + 4),
                              "peak_GBps": HBM_PEAK_GBPS}},
         **({"cpu_baseline": cpu} if cpu else {}),
-    }), flush=True)
+    }
     comm.barrier()
     eng.close()
+    return line
 
 
 def bench_methanation_sweeps(args, pkg, eng, s, n):
@@ -610,6 +670,9 @@ def main():
                          "'auto' (default), an integer, or 0 = one call and one host decision per iteration (round 3's loop)")
     ap.add_argument("--progress", action="store_true",
                     help="methanation only: one line per sweep on stderr and in gpurun_out/bench_methanation_progress.log")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the two extra keys of the default one-GPU line (`exact_mode`: 3 runs in the parity arithmetic; "
+                         "`methanation_n1024`: one complete methanation run at N = 1024 with its own roofline and cpu_baseline)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # no launcher: become one (no GPU call in this process)
@@ -670,6 +733,7 @@ def main():
     elapsed = float(per_rank_s.max())
     rccl = eng.comm_info() if world > 1 else {"count": 0, "user_rank": -1, "device": -1}
     timing = eng.timing_get()
+    work = eng.work_totals()                     # device-counted: solves that produced their outputs, launches that had work
     eng.timing_enable(False)
 
     # steady state (outside the timed region): Metropolis sweeps at gamma = 1 on the final, posterior
@@ -690,10 +754,16 @@ def main():
         dt_ss = time.perf_counter() - ts
         tm_ss = eng.timing_get()
         ss_solve_s = tm_ss["solve"]["ms"] / n_ss * 1e-3
-        ss_tflops = (FLOP_PER_RK_ATTEMPT * att_ss / n_ss + FLOP_PER_PARTICLE_FIXED * n_local) / ss_solve_s / 1e12
+        work_ss = eng.work_totals()
+        if work_ss:    # same numerator as `roofline`: device-counted solves that produced their outputs
+            ss_flop = (FLOP_PER_RK_ATTEMPT * att_ss + FLOP_PER_SOLVED_ITEM * work_ss["solved_items"]) / n_ss + FLOP_PER_PARTICLE_ACCEPT * n_local
+        else:
+            ss_flop = FLOP_PER_RK_ATTEMPT * att_ss / n_ss + FLOP_PER_PARTICLE_FIXED * n_local
+        ss_tflops = ss_flop / ss_solve_s / 1e12
         steady = {"particle_mutation_steps_per_s_wall": n_ss * n_local / dt_ss,
                   "solve_kernel_ms_per_sweep": tm_ss["solve"]["ms"] / n_ss,
                   "sweep_ms_wall": 1e3 * dt_ss / n_ss, "sweeps": n_ss, "rk_attempts_per_sweep": att_ss / n_ss,
+                  "solved_items_per_sweep": work_ss["solved_items"] / n_ss if work_ss else None,
                   "solve_kernel_tflops": ss_tflops, "solve_kernel_roofline_frac": ss_tflops / FP64_VECTOR_PEAK_TFLOPS}
         eng.timing_enable(False)
 
@@ -712,8 +782,21 @@ def main():
         solve_ms = sv["ms"] / max(1, sv["launches"])
         # rank 0's fused-MH launches: algorithmic flop from the device-counted RK45 attempts of those launches
         att = sum(o["stats"]["rk_attempts"] for o in outs)       # all solve launches of the timed region (rank 0)
-        flop_all = FLOP_PER_RK_ATTEMPT * att + FLOP_PER_PARTICLE_FIXED * n_local * sv["launches"]
-        flop_per_launch = flop_all / max(1, sv["launches"])
+        # round 4's numerator, kept one more round next to the honest one: the fixed term for EVERY particle of EVERY enqueued launch
+        flop_all_r4 = FLOP_PER_RK_ATTEMPT * att + FLOP_PER_PARTICLE_FIXED * n_local * sv["launches"]
+        frac_r4 = flop_all_r4 / max(1, sv["launches"]) / (solve_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+        # the honest one: device-counted solves that produced their outputs, launches that had work (the speculative no-op
+        # launches of a batch leave numerator AND launch count; their few microseconds each stay in the time: conservative)
+        launches_work = work["solve_launches"] if work else sv["launches"]
+        assert work is None or work["solve_launches"] + work["noop_launches"] == sv["launches"], (work, sv)
+        assert work is None or work["rk_attempts"] == att, (work, att)
+        if work:
+            flop_all = (FLOP_PER_RK_ATTEMPT * att + FLOP_PER_SOLVED_ITEM * work["solved_items"]
+                        + FLOP_PER_PARTICLE_ACCEPT * n_local * launches_work)
+        else:
+            flop_all = flop_all_r4
+        solve_ms = sv["ms"] / max(1, launches_work)
+        flop_per_launch = flop_all / max(1, launches_work)
         ach_tflops = flop_per_launch / (solve_ms * 1e-3) / 1e12
         hbm_gbps = HBM_BYTES_PER_PARTICLE_SOLVE * n_local / (solve_ms * 1e-3) / 1e9
         ess_ms = timing["ess"]["ms"]
@@ -763,8 +846,14 @@ def main():
                          "frac": ach_tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_source_sha": kernel_source_sha(), "valu_issue": valu, "valu_issue_note": valu_note,
                          "peak_measured_fp64_fma_tflops": measured_fp64_peak()[0], "peak_measured_note": measured_fp64_peak()[1],
-                         "avg_launch_ms": solve_ms, "launches": sv["launches"], "mh_sweep_avg_ms": mh_ms,
+                         "avg_launch_ms": solve_ms, "launches": launches_work, "launches_enqueued": sv["launches"],
+                         "launches_noop": sv["launches"] - launches_work, "mh_sweep_avg_ms": mh_ms,
                          "algorithmic_flop_per_launch": flop_per_launch,
+                         "numerator": "100 flop x device-counted RK45 attempts + 732 flop x device-counted solves that produced their "
+                                      "40 outputs + 50 flop x particles of the launches that had work; no-op launches excluded from "
+                                      "numerator and launch count",
+                         "device_counts": work, "rk_attempts": att,
+                         "frac_round4_formula": frac_r4,
                          "hbm": {"algorithmic_bytes_per_launch": HBM_BYTES_PER_PARTICLE_SOLVE * n_local,
                                  "achieved_GBps": hbm_gbps, "peak_GBps": HBM_PEAK_GBPS,
                                  "frac": hbm_gbps / HBM_PEAK_GBPS},
@@ -780,6 +869,27 @@ def main():
                              "peak_GBps": HBM_PEAK_GBPS,
                              "exp_per_s": (ess_iters * n_local) / (ess_ms * 1e-3) if ess_ms > 0 else None},
         }
+        if world == 1 and not args.no_extra and not args.exact:
+            # Two more measurements in the SAME process, after the headline's timed region: the price of the
+            # parity arithmetic, and the methanation workload's line at N = 1024 - so that both are driver-run numbers
+            s_exact = pkg.SMCSettings(**{**s.__dict__, "exact_pow": True})
+            one = lambda i: pkg.run_smc(eng, s_exact, comm=comm, rng="device", verbose=False, seed_device=1000 + i)   # noqa: E731
+            one(-1)
+            eng.synchronize()
+            tx = time.perf_counter()
+            ox = [one(i) for i in range(3)]
+            eng.synchronize()
+            dx = (time.perf_counter() - tx) / 3
+            result["exact_mode"] = {
+                "ms_per_step": 1e3 * dx, "runs": 3, "ratio_to_default": 1e3 * dx / result["ms_per_step"],
+                "value": sum(o["stats"]["particle_mutation_steps"] for o in ox) / (3 * dx),
+                "arithmetic": "smc_set_exact_pow(1): correctly rounded pow(x, -0.2) in the step controller, separately rounded stage "
+                              "sums - the instantiation pinned to the reference (equal RK45 step sequences, <= 1e-9 on logL)",
+                "same_seeds_as_headline_runs": [1000, 1001, 1002],
+                "tempering_steps_per_run": [o["step"] for o in ox], "logZ": [o["logZ"] for o in ox]}
+            eng.set_exact_pow(False)
+            m_args = argparse.Namespace(**{**vars(args), "meth_sweeps": 0, "progress": False})
+            result["methanation_n1024"] = methanation_line(m_args, 1024, 1, 0, cpu_seconds=0.0 if args.no_cpu_baseline else 4.0)
         if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result), flush=True)

@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define SMC_ABI_VERSION 2    /* 2: smc_meth_sweep_check writes FIVE words (round 3 added the cancelled count); smc_mh_sweeps_device_rng */
+#define SMC_ABI_VERSION 3    /* 2: smc_meth_sweep_check writes FIVE words (round 3 added the cancelled count); smc_mh_sweeps_device_rng
+                              * 3: smc_work_totals; smc_mh_sweeps_device_rng takes every model (round 5) */
 #define SMC_MAX_DIM 8        /* parameters per particle (3 for Michaelis-Menten, 5 for methanation) */
 #define SMC_MAX_ESS_CAND 16  /* tempering candidates evaluated by one smc_ess_partials call */
 #define SMC_MAX_RANKS 64
@@ -412,6 +413,13 @@ int smc_resample_phase3_pull(smc_ctx *ctx);
 int smc_timing_enable(smc_ctx *ctx, int enable);
 int smc_timing_reset(smc_ctx *ctx);
 int smc_timing_get(smc_ctx *ctx, int which, int64_t *launches, double *total_ms);
+/* Device-counted work of the Michaelis-Menten sweeps since the last smc_timing_reset (always on; bench.py's roofline numerator):
+ * out[0] (particle, experiment) solves that ran to t_bound and produced their n_t dense outputs - cancelled (exact early
+ *        rejection) and masked (out of support) proposals do not count;
+ * out[1] RK45 attempts of all solves, finished or cancelled;
+ * out[2] launches of the solve kernel that had work;  out[3] launches of a speculative batch (smc_mh_sweeps_device_rng) that
+ *        found the loop already ended and returned at once. */
+int smc_work_totals(smc_ctx *ctx, int64_t out[4]);
 
 /* ---- methanation model (configs 4-5): context-free building blocks ---------------------------------------
  * State layout as in the reference: 357 = 7 fields x 51 axial nodes, field-major X[f*51+i],

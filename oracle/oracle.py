@@ -354,12 +354,18 @@ class StepRecord:
 
 
 def run_smc(data: MMData, s: SMCSettings | None = None, seed: int | None = 20250205, loglik="c", n_threads=0,
-            record_mh=True, verbose=False, p_pred0=None):
+            record_mh=True, verbose=False, p_pred0=None, resample_impl="c"):
     """The reference's driver (Micmem_SMC_main.py:95-262) statement by statement on the global NumPy RNG.
 
     seed=None leaves the global stream as it is.  Returns dict with final particles, lk, per-step records,
     every likelihood sweep (inputs/outputs, in order) and log-evidence.
+
+    resample_impl="python" runs the resampling loop as the reference writes it, in pure Python (main:147-184) - with
+    loglik="scipy" that makes the whole run the NumPy/SciPy counterpart bench.py times as `cpu_baseline` (SURVEY.md 8(d)(i));
+    `stage_s` in the result holds the wall time of the likelihood sweeps, the ESS searches and the resampling loops.
     """
+    import time as _time
+    stage_s = {"likelihood": 0.0, "ess_search": 0.0, "resample": 0.0}
     s = s or SMCSettings()
     n_particle = s.n_particle
     d = s.num_est_params
@@ -368,6 +374,13 @@ def run_smc(data: MMData, s: SMCSettings | None = None, seed: int | None = 20250
     sweeps = []
 
     def sim_particle(p):
+        t_in = _time.perf_counter()
+        try:
+            return _sim_particle(p)
+        finally:
+            stage_s["likelihood"] += _time.perf_counter() - t_in
+
+    def _sim_particle(p):
         if loglik == "c":
             lk_, _, info = mm_loglik_batch(p, data, s.est_sigma, s.sigma_true, s.rtol, s.atol, n_threads=n_threads)
             if info["n_failed"]:
@@ -393,7 +406,9 @@ def run_smc(data: MMData, s: SMCSettings | None = None, seed: int | None = 20250
     n_ess_iters = 0
     step = 0
     for step in range(1, s.itr_max):               # :109
+        t_in = _time.perf_counter()
         es = ess_search(lk, gamma_old, s)          # :111-144
+        stage_s["ess_search"] += _time.perf_counter() - t_in
         gamma_new, ess, p_weight, max_lk = es["gamma_new"], es["ess"], es["p_weight"], es["max_lk"]
         n_ess_iters += es["iters"]
         # log-evidence increment (not in the reference):
@@ -401,7 +416,9 @@ def run_smc(data: MMData, s: SMCSettings | None = None, seed: int | None = 20250
         dlogZ = es["gm"] * max_lk + math.log(es["sum_weight"] / n_particle)
         logZ += dlogZ
         wrand_u = np.random.rand()                 # :156
-        p_is, n_written, n_tmp = resample(p_weight, wrand_u, p_pred, lk, p_filt, lk1)   # :147-184
+        t_in = _time.perf_counter()
+        p_is, n_written, n_tmp = (resample_python if resample_impl == "python" else resample)(p_weight, wrand_u, p_pred, lk, p_filt, lk1)   # :147-184
+        stage_s["resample"] += _time.perf_counter() - t_in
         r_ac = np.zeros(n_particle)                # :187
         mhstep_ratio = 1.0                         # :190
         if gamma_new >= 1.0:                       # :193-208
@@ -457,4 +474,4 @@ def run_smc(data: MMData, s: SMCSettings | None = None, seed: int | None = 20250
             break
         gamma_old = gamma_new
     return {"p_pred": p_pred, "lk": lk, "records": records, "sweeps": sweeps, "logZ": logZ, "gamma": gamma_new,
-            "step": step, "n_mutation_sweeps": n_mutation_sweeps, "n_ess_iters": n_ess_iters}
+            "step": step, "n_mutation_sweeps": n_mutation_sweeps, "n_ess_iters": n_ess_iters, "stage_s": stage_s}

@@ -20,7 +20,7 @@ SMC_PRIOR_MODE_MASK, SMC_PRIOR_MODE_RATIO_MASK, SMC_PRIOR_MODE_RATIO = 0, 1, 2
 PRIOR_MODES = {"mask": 0, "ratio_mask": 1, "ratio": 2}
 RESAMPLING = {"residual_systematic": 0, "systematic": 1, "multinomial": 2}
 SMC_MAX_ESS_CAND = 16
-SMC_ABI_VERSION = 2
+SMC_ABI_VERSION = 3
 SMC_MH_BATCH_MAX = 32
 SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX, SMC_T_SOLVE = range(7)
 TIMING_NAMES = {SMC_T_LOGLIK: "loglik", SMC_T_MH: "mh", SMC_T_ESS: "ess", SMC_T_RESAMPLE: "resample",
@@ -116,6 +116,7 @@ SIGNATURES = {
     "smc_timing_enable": (cint, [c_ctx, cint]),
     "smc_timing_reset": (cint, [c_ctx]),
     "smc_timing_get": (cint, [c_ctx, cint, c_i64p, c_dp]),
+    "smc_work_totals": (cint, [c_ctx, c_i64p]),
     "smc_meth_last_error": (ctypes.c_char_p, []),
     "smc_meth_residual_host": (cint, [cint, c_dp, c_dp, c_dp, i64, c_dp]),
     "smc_meth_rate_host": (cint, [cint, c_dp, c_dp, i64, c_dp]),
@@ -158,7 +159,10 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         ver = L.smc_abi_version()
-        if ver != SMC_ABI_VERSION and not (os.environ.get("SMC_HIP_LIB") and ver == 1):   # an A/B build of round 3 is version 1
+        # an A/B build of an older revision (SMC_HIP_LIB) is accepted from version 2 on (round 4: every entry point the default
+        # driver path calls exists there; a call to a newer one raises through MISSING); version 1 lacks smc_resample_enqueue
+        # and smc_mh_sweeps_device_rng, which run_smc uses by default, and is refused
+        if ver != SMC_ABI_VERSION and not (os.environ.get("SMC_HIP_LIB") and 2 <= ver < SMC_ABI_VERSION):
             raise SmcError(f"libsmc_hip.so ABI version mismatch: library {ver}, binding {SMC_ABI_VERSION}")
         _LIB = L
     return _LIB

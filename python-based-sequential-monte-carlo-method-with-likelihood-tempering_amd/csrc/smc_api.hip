@@ -587,6 +587,11 @@ static int counters_begin(smc_ctx *c) {
 static int counters_end(smc_ctx *c) {
     HIPC(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(SweepCounters), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->model_kind == 1) {   // smc_work_totals: every sweep that ends here launched the solve kernel once
+        c->w_solved_items += (int64_t)c->h_counters->solved_items;
+        c->w_rk_attempts += (int64_t)c->h_counters->rk_attempts;
+        c->w_solve_launches += 1;
+    }
     if (c->model_kind == 1 && c->pending_sweep_items > 0) {   // what the next Metropolis sweep's in-phase decision looks at
         c->last_sweep_items = c->pending_sweep_items;
         c->last_sweep_long_items = (int64_t)c->h_counters->long_items;
@@ -1442,8 +1447,12 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
     if (n_done) *n_done = done;
     if (stopped) *stopped = c->h_mhctl->stop;
     if (ratio_next) *ratio_next = c->h_mhctl->ratio;
+    c->w_solve_launches += done;
+    c->w_noop_launches += n_iter - done;
     for (int i = 0; i < done; ++i) {
         const MHLogEntry &e = c->h_mhlog[i];
+        c->w_solved_items += (int64_t)e.solved_items;
+        c->w_rk_attempts += (int64_t)e.rk_attempts;
         if (accepted_now) accepted_now[i] = (int64_t)e.accepted_now;
         if (accepted_ever) accepted_ever[i] = (int64_t)e.accepted_ever;
         if (n_failed) n_failed[i] = (int64_t)e.n_failed;
@@ -1611,6 +1620,7 @@ int smc_timing_reset(smc_ctx *c) {
         c->t_launches[i] = 0;
         c->t_ms[i] = 0.0;
     }
+    c->w_solved_items = c->w_rk_attempts = c->w_solve_launches = c->w_noop_launches = 0;
     return 0;
 }
 int smc_timing_get(smc_ctx *c, int which, int64_t *launches, double *total_ms) {
@@ -1620,6 +1630,15 @@ int smc_timing_get(smc_ctx *c, int which, int64_t *launches, double *total_ms) {
     timing_collect(c);
     if (launches) *launches = c->t_launches[which];
     if (total_ms) *total_ms = c->t_ms[which];
+    return 0;
+}
+int smc_work_totals(smc_ctx *c, int64_t out[4]) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (!out) return fail(c, "smc_work_totals: out is NULL");
+    out[0] = c->w_solved_items;
+    out[1] = c->w_rk_attempts;
+    out[2] = c->w_solve_launches;
+    out[3] = c->w_noop_launches;
     return 0;
 }
 

@@ -78,6 +78,7 @@ struct MHLogEntry {             // what the driver's Python kept per iteration (
     double ratio;               // mhstep_ratio the iteration drew its proposals with
     double accepted_now, accepted_ever, n_failed;   // totals over all ranks
     unsigned long long rk_attempts, long_items;     // this rank's
+    unsigned long long solved_items;                // this rank's: solves of the iteration that ran to the end (not cancelled, not masked)
     double cov[SMC_MAX_DIM * SMC_MAX_DIM];          // cov_m of the iteration (:212-215)
 };
 constexpr int kMHBatchMax = 32;                     // iterations per batch (ad_mhstep_num is 20)
@@ -141,6 +142,7 @@ struct SweepCounters {  // device-side integer counters (order-independent atomi
     unsigned long long expected_solves, completed_solves, unsolved_items, wave_split;
     unsigned long long cancelled_solves;   // solves not started because their proposal was already certain to be rejected
     unsigned long long long_items;         // Michaelis-Menten: items that needed more than kLongItemAttempts attempts (mm_kernels.hip)
+    unsigned long long solved_items;       // Michaelis-Menten: (particle, experiment) solves that reached t_bound and produced their dense outputs
 };
 
 struct EventPair {
@@ -258,6 +260,9 @@ struct smc_ctx {
     std::vector<smc::EventPair> ev_free;
     int64_t t_launches[SMC_T_COUNT]{};
     double t_ms[SMC_T_COUNT]{};
+    // work totals since smc_timing_reset (smc_work_totals): Michaelis-Menten solves that produced their outputs, RK45 attempts, solve
+    // launches that had work, solve launches of a speculative batch that found the loop ended
+    int64_t w_solved_items = 0, w_rk_attempts = 0, w_solve_launches = 0, w_noop_launches = 0;
 };
 
 namespace smc {

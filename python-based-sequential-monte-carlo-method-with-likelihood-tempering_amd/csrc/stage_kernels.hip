@@ -477,6 +477,7 @@ __global__ void __launch_bounds__(kScanBlock) mh_control_kernel(MHControlArgs a,
         e.n_failed = n_failed;
         e.rk_attempts = a.counters->rk_attempts;       // this rank's
         e.long_items = a.counters->long_items;
+        e.solved_items = a.counters->solved_items;
         ctl->n_done = a.iteration;
         if (acc_ever > ctl->thr_stop || n_failed != 0.0) {
             ctl->stop = 1;

@@ -584,3 +584,12 @@ class HipEngine:
             self._ck(self.L.smc_timing_get(self.ctx, which, ctypes.byref(n), ctypes.byref(ms)), "smc_timing_get")
             out[name] = {"launches": n.value, "ms": ms.value}
         return out
+
+    def work_totals(self):
+        """Device-counted Michaelis-Menten work since timing_reset(): solves that produced their outputs, RK45 attempts, solve
+        launches with work, speculative launches that found the loop ended (smc_work_totals)."""
+        if "smc_work_totals" in B.MISSING:         # A/B build of an older revision (SMC_HIP_LIB)
+            return None
+        out = (ctypes.c_int64 * 4)()
+        self._ck(self.L.smc_work_totals(self.ctx, out), "smc_work_totals")
+        return {"solved_items": out[0], "rk_attempts": out[1], "solve_launches": out[2], "noop_launches": out[3]}

@@ -18,9 +18,9 @@ def test_library_exports_every_declared_symbol(pkg):
     missing = [s for s in declared if not hasattr(L, s)]
     assert not missing, missing
     assert set(declared) == set(pkg.binding.SIGNATURES), set(declared) ^ set(pkg.binding.SIGNATURES)
-    assert L.smc_abi_version() == pkg.binding.SMC_ABI_VERSION == 2      # 2: smc_meth_sweep_check writes five words
+    assert L.smc_abi_version() == pkg.binding.SMC_ABI_VERSION == 3      # 3: smc_work_totals, batched Metropolis loop for every model (round 5)
     hdr = open(pkg.binding.HEADER_PATH).read()
-    assert "#define SMC_ABI_VERSION 2" in hdr
+    assert "#define SMC_ABI_VERSION 3" in hdr
 
 
 def test_exported_symbols_are_plain_c(pkg):

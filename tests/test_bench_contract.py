@@ -28,6 +28,17 @@ def test_bench_prints_one_json_line_with_the_contract_fields(extra):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if not extra:
+        # the roofline numerator is device-counted: solves that produced their outputs, launches with work
+        w = r["device_counts"]
+        assert w["solve_launches"] + w["noop_launches"] == r["launches_enqueued"] and r["launches"] == w["solve_launches"]
+        assert 0 < w["solved_items"] <= 6 * 20000 * w["solve_launches"] and w["rk_attempts"] == r["rk_attempts"]
+        assert r["frac"] <= r["frac_round4_formula"]
+        # ... and the default one-GPU line carries the parity-arithmetic runs and the methanation line (item 2b)
+        x, m = d["exact_mode"], d["methanation_n1024"]
+        assert x["runs"] == 3 and x["ms_per_step"] > 0 and x["ratio_to_default"] > 0.5
+        assert m["config"]["particles_per_gpu"] == 1024 and m["value"] > 0 and m["roofline"]["frac"] > 0
+        assert m["dae_solves"] > 0 and set(m["per_solve"]) == {"bdf_steps", "newton_iters", "factorisations"}
 
 
 # ---- N > 1 launch plumbing, no GPU needed -------------------------------------------------------------------------------
