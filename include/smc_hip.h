@@ -396,6 +396,12 @@ int smc_debug_rccl_self_exchange(smc_ctx *ctx, int64_t row, int64_t cnt, int64_t
  * device) instead of the RCCL send/recv pairs.  Everything else (kernels, offsets, counts) is the RCCL path. */
 int smc_debug_set_local_peers(smc_ctx *ctx, smc_ctx **peers, int rank, int world);
 int smc_resample_phase3_pull(smc_ctx *ctx);
+/* ... and with the collectives INSIDE the engine (after smc_debug_set_local_peers on every peer, at most 8): the *_global entry
+ * points, smc_resample_enqueue, smc_mh_iteration_device_rng and smc_mh_sweeps_device_rng then take their world > 1 branches with
+ * every ncclAllReduce / ncclAllGather / send-recv pair replaced by its counterpart among the peer contexts (events between
+ * their streams, a host barrier between their threads; sums in rank order) - the stop / no-op logic of a speculative batch and
+ * the matched reductions run bit for bit as they would over RCCL.  Every peer thread must make the same calls. */
+int smc_debug_peer_collectives(smc_ctx *ctx, int enable);
 #endif /* SMC_ENABLE_DEBUG_API */
 
 /* ---- measurement ------------------------------------------------------------------------------ */
@@ -444,7 +450,8 @@ int smc_meth_loglike_host(int device, const double *y, const double *data, const
  * standard-state flows (:204-208).  PARITY UNPINNED against IDA (see csrc/meth_dae.h).  A failed solve
  * (status != 0) returns the reference's sentinel flows -10000 (:244-249).
  * p0_all: n_solves x 18, y0_all: n_solves x 357, flows: n_solves x 5, y_final (optional): n_solves x 357,
- * status: n_solves, stats (optional): sums of steps, rejected steps, Newton failures, Newton iterations. */
+ * status: n_solves, stats (optional, FIVE words since ABI 3): sums of steps, rejected steps, Newton failures, Newton iterations,
+ * factorisations of the iteration matrix. */
 int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, int64_t n_solves, double tf, double rtol,
                       double atol, double h0, double S, double P_stp, double *flows, double *y_final, int32_t *status,
                       int64_t *stats, double *kernel_ms);

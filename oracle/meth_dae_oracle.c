@@ -176,13 +176,43 @@ static void change_D(double D[][NS], int order, double factor, int n) {
 }
 
 /*
+ * Control policy of the integrator (round 5).  The DEFAULT (all zero) is the checker of rounds 1-4: SciPy's BDF control with the
+ * iteration matrix evaluated at the predictor of every attempt.  The other settings restate, inside the same quasi-constant-step
+ * BDF, the control policy of IDA, the reference's actual integrator (SUNDIALS IDA, "Mathematical considerations"; Assimulo
+ * configures it at methanation_set_likelihood.py:167-198) - K8 uses them (csrc/meth_dae_elem.h), and this file is the CPU
+ * statement of what K8 does, compared with the default policy and with tight-tolerance runs (tests/test_methanation_dae.py):
+ *   reuse   0  iteration matrix at the predictor of every attempt
+ *           1  kept while c = h / alpha_k is unchanged (SciPy; K8 of rounds 1-4)
+ *           2  kept while cj / cj_at_evaluation stays inside ((1 - xrate) / (1 + xrate), (1 + xrate) / (1 - xrate)), xrate = 0.25,
+ *              i.e. (0.6, 1.667), the Newton correction scaled by 2 / (1 + cjratio)  (IDA: idaNls, idaLsSolve)
+ *   newton  0  SciPy's test: rate / (1 - rate) * |dy| < newton_tol = max(10 eps / rtol, min(0.03, sqrt(rtol))), rate from two
+ *              iterations of THIS step
+ *           1  IDA's: converged when ss * |dy| <= epcon (0.33); ss = rate / (1 - rate) is CARRIED from step to step, reset to 20
+ *              when the matrix is evaluated and to 100 when cj changed since the previous step; first iteration also converges
+ *              on |dy| <= 1e-4 epcon; rate = (|dy_m| / |dy_0|)^(1/m) > 0.9 fails the iteration
+ *   stepctl 0  SciPy: after order + 1 equal steps, h *= min(10, safety * best factor) whatever the factor
+ *           1  IDA: h doubles when the factor is >= 2, shrinks by clamp(factor, 0.5, 0.9) when it is < 1, and is otherwise KEPT
+ *           2  as 1, but a factor >= 2 is applied as SciPy would (min(10, ...)): the start-up phase stays short
+ */
+typedef struct {
+    int32_t reuse, newton, stepctl, reserved;
+    double epcon, xrate;
+} dae_policy;
+
+typedef struct {
+    int64_t newton_iters, stale_retries;
+} dae_stats_ext;
+
+/*
  * Integrate F(y, y'; p) = 0 from (0, y0) with y'(0) = 0 to tf.  diff_mask[i] = 1 for differential variables
  * (error test), n = number of active unknowns (<= NS; the generic entry is used by the unit test on an ODE).
  */
-int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p, int n, int n_fields,
-                      const unsigned char *diff_mask, double tf, double rtol, double atol, double h0, double *y_out,
-                      dae_stats *st) {
+int dae_bdf_integrate_policy(resid_fn F, void *user, const double *y0, const double *p, int n, int n_fields,
+                             const unsigned char *diff_mask, double tf, double rtol, double atol, double h0, double *y_out,
+                             dae_stats *st, const dae_policy *pol, dae_stats_ext *ext) {
     static const double kappa[6] = {0, -0.1850, -1.0 / 9, -0.0823, -0.0415, 0};
+    static const dae_policy checker = {0, 0, 0, 0, 0.33, 0.25};
+    if (!pol) pol = &checker;
     double gamma[6], alpha[6], error_const[7];
     gamma[0] = 0.0;
     for (int k = 1; k <= MAX_ORDER; ++k) gamma[k] = gamma[k - 1] + 1.0 / k;
@@ -195,11 +225,15 @@ int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p,
     int piv[NS];
     double y_pred[NS], psi[NS], scale[NS], y[NS], d[NS], r[NS], dy[NS], ydot[NS], tmpv[NS];
     memset(st, 0, sizeof *st);
+    if (ext) memset(ext, 0, sizeof *ext);
     memcpy(D[0], y0, sizeof(double) * NS);
     const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+    const double cj_lo = (1 - pol->xrate) / (1 + pol->xrate), cj_hi = 1.0 / cj_lo;
     double t = 0.0, h_abs = h0;
     int order = 1, n_equal = 0, rc = 0;
     const int64_t max_steps = 200000;
+    int lu_valid = 0, force_rebuild = 0;
+    double c_lu = 0.0, c_last = 0.0, ss = 20.0;
 
     while (t < tf && rc == 0) {
         int accepted = 0, n_iter = 0;
@@ -223,19 +257,38 @@ int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p,
                 scale[i] = atol + rtol * fabs(s);
             }
             const double c = h / alpha[order];
-            /* iteration matrix at the predictor, every step */
-            for (int i = 0; i < NS; ++i) ydot[i] = psi[i] / c;
-            iteration_matrix(F, user, y_pred, ydot, p, c, ab, n_fields, &st->nres);
-            st->nlu++;
+            int fresh;
+            if (pol->reuse == 0) fresh = 1;
+            else if (pol->reuse == 1) fresh = !lu_valid || c != c_lu || force_rebuild;
+            else {
+                const double cjratio = c_lu / c;   /* cj / cj_old, cj = 1 / c */
+                fresh = !lu_valid || force_rebuild || !(cjratio > cj_lo && cjratio < cj_hi);
+            }
+            if (pol->newton == 1 && c != c_last) ss = 100.0;
+            c_last = c;
+            int factored = lu_valid;
+            if (fresh) {
+                /* iteration matrix at the predictor */
+                for (int i = 0; i < NS; ++i) ydot[i] = psi[i] / c;
+                iteration_matrix(F, user, y_pred, ydot, p, c, ab, n_fields, &st->nres);
+                st->nlu++;
+                factored = band_factor(ab, piv, NS) == 0;
+                lu_valid = factored;
+                c_lu = c;
+                force_rebuild = 0;
+                ss = 20.0;
+            }
+            const double corr_scale = (pol->reuse == 2) ? 2.0 / (1.0 + c_lu / c) : 1.0;
             int converged = 0;
-            if (band_factor(ab, piv, NS) == 0) {
+            if (factored) {
                 memcpy(y, y_pred, sizeof y);
                 memset(d, 0, sizeof d);
-                double dy_norm_old = -1.0;
+                double dy_norm_old = -1.0, dy_norm_first = 0.0;
                 for (int k = 0; k < NEWTON_MAXITER; ++k) {
                     for (int i = 0; i < NS; ++i) ydot[i] = (psi[i] + d[i]) / c;
                     F(y, ydot, p, r, user);
                     st->nres++;
+                    if (ext) ext->newton_iters++;
                     n_iter = k + 1;
                     int finite = 1;
                     for (int i = 0; i < n; ++i)
@@ -246,18 +299,38 @@ int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p,
                         tmpv[k2] = (fm < n) ? -r[fm] : 0.0;
                     }
                     band_solve(ab, piv, NS, tmpv);
-                    for (int k2 = 0; k2 < NS; ++k2) dy[fm_of_nm(k2)] = tmpv[k2];
+                    for (int k2 = 0; k2 < NS; ++k2) dy[fm_of_nm(k2)] = tmpv[k2] * corr_scale;
                     const double dy_norm = rms_masked(dy, scale, NULL, n);
-                    double rate = -1.0;
-                    if (dy_norm_old >= 0) rate = dy_norm / dy_norm_old;
-                    if (rate >= 0 && (rate >= 1 || pow(rate, NEWTON_MAXITER - k) / (1 - rate) * dy_norm > newton_tol)) break;
-                    for (int i = 0; i < n; ++i) { y[i] += dy[i]; d[i] += dy[i]; }
-                    if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = 1; break; }
-                    dy_norm_old = dy_norm;
+                    if (pol->newton == 0) {
+                        double rate = -1.0;
+                        if (dy_norm_old >= 0) rate = dy_norm / dy_norm_old;
+                        if (rate >= 0 && (rate >= 1 || pow(rate, NEWTON_MAXITER - k) / (1 - rate) * dy_norm > newton_tol)) break;
+                        for (int i = 0; i < n; ++i) { y[i] += dy[i]; d[i] += dy[i]; }
+                        if (dy_norm == 0 || (rate >= 0 && rate / (1 - rate) * dy_norm < newton_tol)) { converged = 1; break; }
+                        dy_norm_old = dy_norm;
+                    } else {
+                        for (int i = 0; i < n; ++i) { y[i] += dy[i]; d[i] += dy[i]; }
+                        if (k == 0) {
+                            dy_norm_first = dy_norm;
+                            if (dy_norm <= 1e-4 * pol->epcon) { converged = 1; break; }
+                        } else {
+                            const double q = dy_norm / dy_norm_first;
+                            const double rate = (k == 1) ? q : (k == 2) ? sqrt(q) : cbrt(q);
+                            if (!(rate <= 0.9)) break;
+                            ss = rate / (1.0 - rate);
+                        }
+                        if (ss * dy_norm <= pol->epcon) { converged = 1; break; }
+                    }
                 }
+            }
+            if (!converged && !fresh) { /* stale matrix: the same attempt again with a fresh one */
+                force_rebuild = 1;
+                if (ext) ext->stale_retries++;
+                continue;
             }
             if (!converged) {
                 st->newton_fail++;
+                lu_valid = 0;
                 h_abs *= 0.5;
                 change_D(D, order, 0.5, NS);
                 n_equal = 0;
@@ -302,8 +375,19 @@ int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p,
         delta = -1;
         if (f0 > best) { best = f0; delta = 0; }
         if (fp > best) { best = fp; delta = 1; }
-        order += delta;
         double factor = fmin(10.0, safety * best);
+        if (pol->stepctl != 0) {
+            if (factor >= 2.0) factor = (pol->stepctl == 1) ? 2.0 : factor;
+            else if (factor < 1.0) factor = fmax(0.5, fmin(0.9, factor));
+            else factor = 1.0;
+        }
+        if (pol->stepctl != 0 && factor == 1.0) {
+            /* the step size stays: the differences of the new order are valid as they are (R(1) U = I); n_equal keeps counting,
+             * so the selection is looked at again after the next step */
+            order += delta;
+            continue;
+        }
+        order += delta;
         h_abs *= factor;
         change_D(D, order, factor, NS);
         n_equal = 0;
@@ -313,6 +397,20 @@ int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p,
     free(D);
     free(ab);
     return rc;
+}
+
+int dae_bdf_integrate(resid_fn F, void *user, const double *y0, const double *p, int n, int n_fields,
+                      const unsigned char *diff_mask, double tf, double rtol, double atol, double h0, double *y_out,
+                      dae_stats *st) {
+    return dae_bdf_integrate_policy(F, user, y0, p, n, n_fields, diff_mask, tf, rtol, atol, h0, y_out, st, NULL, NULL);
+}
+
+/* the methanation DAE under a given control policy (NULL: the checker's default) */
+int meth_dae_solve_policy(const double *y0, const double *p, double tf, double rtol, double atol, double h0, double *y_out,
+                          dae_stats *st, const dae_policy *pol, dae_stats_ext *ext) {
+    unsigned char mask[NS];
+    for (int i = 0; i < NS; ++i) mask[i] = (i < 6 * NX);
+    return dae_bdf_integrate_policy(meth_resid, NULL, y0, p, NS, 7, mask, tf, rtol, atol, h0, y_out, st, pol, ext);
 }
 
 /* my_model (methanation_set_likelihood.py:144-277) for ONE experiment: integrate, map the outlet node to the

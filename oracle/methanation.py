@@ -169,8 +169,39 @@ class DaeStats(ctypes.Structure):
                 "newton_fail": self.newton_fail, "status": self.status, "order_hist": list(self.order_hist)}
 
 
+class DaePolicy(ctypes.Structure):
+    """Control policy of the BDF integrator (oracle/meth_dae_oracle.c: dae_policy).  The default of the C side (NULL) is the
+    checker of rounds 1-4; K8_POLICY is what the HIP kernel K8 does since round 5 (csrc/meth_dae_elem.h: SMC_K8_POLICY 1)."""
+    _fields_ = [("reuse", ctypes.c_int32), ("newton", ctypes.c_int32), ("stepctl", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("epcon", ctypes.c_double), ("xrate", ctypes.c_double)]
+
+
+class DaeStatsExt(ctypes.Structure):
+    _fields_ = [("newton_iters", ctypes.c_int64), ("stale_retries", ctypes.c_int64)]
+
+
+def k8_policy():
+    return DaePolicy(2, 1, 0, 0, 0.33, 0.15)
+
+
+def dae_solve_policy(y0, p, policy=None, tf=75.0, rtol=1e-6, atol=1e-6, h0=1e-5):
+    """dae_solve under a control policy (None: the checker's default); the stats carry Newton iterations and stale retries."""
+    y0 = np.ascontiguousarray(y0, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.empty(7 * NX)
+    st, ext = DaeStats(), DaeStatsExt()
+    rc = _dae_lib().meth_dae_solve_policy(_p(y0), _p(p), tf, rtol, atol, h0, _p(out), ctypes.byref(st),
+                                          ctypes.byref(policy) if policy is not None else None, ctypes.byref(ext))
+    d = st.asdict()
+    d.update(newton_iters=ext.newton_iters, stale_retries=ext.stale_retries)
+    return out, rc, d
+
+
 def _dae_lib():
     L = lib()
+    L.meth_dae_solve_policy.restype = ctypes.c_int
+    L.meth_dae_solve_policy.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp,
+                                        ctypes.POINTER(DaeStats), ctypes.POINTER(DaePolicy), ctypes.POINTER(DaeStatsExt)]
     L.meth_dae_solve.restype = ctypes.c_int
     L.meth_dae_solve.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp,
                                  ctypes.POINTER(DaeStats)]

@@ -113,6 +113,7 @@ SIGNATURES = {
     "smc_debug_rccl_self_exchange": (cint, [c_ctx, i64, i64, i64]),
     "smc_debug_set_local_peers": (cint, [c_ctx, ctypes.POINTER(c_ctx), cint, cint]),
     "smc_resample_phase3_pull": (cint, [c_ctx]),
+    "smc_debug_peer_collectives": (cint, [c_ctx, cint]),
     "smc_timing_enable": (cint, [c_ctx, cint]),
     "smc_timing_reset": (cint, [c_ctx]),
     "smc_timing_get": (cint, [c_ctx, cint, c_i64p, c_dp]),

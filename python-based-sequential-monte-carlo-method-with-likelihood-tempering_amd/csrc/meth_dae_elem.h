@@ -173,6 +173,60 @@ __device__ __forceinline__ double ipow_small(double x, int n) {   // x^n, 1 <= n
     return r;
 }
 
+// ---- control policy of the integrator (round 5; CPU statement and study: oracle/meth_dae_oracle.c dae_policy,
+// tools/k8_policy_study.py) ----------------------------------------------------------------------------------------------
+// SMC_K8_POLICY 1 (default): IDA's policy for the iteration matrix and the Newton iteration, restated inside the
+// quasi-constant-step BDF (the reference integrates with IDA: methanation_set_likelihood.py:167-198; SUNDIALS IDA,
+// "Mathematical considerations", idaNls / idaNewtonIter / idaLsSolve):
+//   * the factored iteration matrix is kept while cj / cj_at_evaluation stays inside ((1 - xrate) / (1 + xrate), its reciprocal),
+//     xrate = SMC_K8_XRATE (IDA: 0.25; here 0.15, by measurement), and the Newton correction is scaled by 2 / (1 + cjratio); a Newton failure on a kept matrix repeats
+//     the attempt with a fresh one;
+//   * Newton converges when ss * |dy| <= 0.33 (|.| = RMS over all unknowns in tolerance units), ss = rate / (1 - rate) CARRIED
+//     from step to step (20 after an evaluation of the matrix, 100 when cj changed since the previous attempt); the first
+//     iteration also converges on |dy| <= 0.33e-4; rate = (|dy_m| / |dy_0|)^(1/m) > 0.9 ends the iteration as failed.
+// IDA's step-size rule (double at a factor >= 2, hold below that) was studied as well and is NOT adopted: in this formulation it
+// costs 30 % more steps (profiles/r05_k8_policy_study_cpu.txt).
+// SMC_K8_POLICY 0: rounds 1-4 (SciPy's bdf.py: matrix kept only while c is unchanged, convergence rate from two iterations of
+// the same step, newton_tol = 1e-3) - A/B builds.
+#ifndef SMC_K8_POLICY
+#define SMC_K8_POLICY 1
+#endif
+#ifndef SMC_K8_XRATE
+#define SMC_K8_XRATE 0.15    // IDA's own window is 0.25; measured on one box (profiles/r05_ab_k8_policy.log): 2048 x 30 solves at
+#endif                       // 0.25 -> 137.8 k solves/s, 0.15 -> 145.1 k, 0.10 -> 141.8 k (rounds 1-4's policy: 103.8 k)
+constexpr double kEpcon = 0.33, kRateMax = 0.9, kSsAfterSetup = 20.0, kSsAfterCjChange = 100.0;
+constexpr double kCjRatioLo = (1.0 - SMC_K8_XRATE) / (1.0 + SMC_K8_XRATE), kCjRatioHi = (1.0 + SMC_K8_XRATE) / (1.0 - SMC_K8_XRATE);
+// must the matrix evaluated at c_lu be evaluated again for an attempt with c?  (cj = 1 / c: cjratio = c_lu / c)
+__device__ __forceinline__ bool matrix_is_stale(double c, double c_lu) {
+#if SMC_K8_POLICY
+    const double cjratio = c_lu / c;
+    return !(cjratio > kCjRatioLo && cjratio < kCjRatioHi);
+#else
+    return c != c_lu;
+#endif
+}
+// scale of the Newton correction computed with the matrix of c_lu in an attempt with c (exactly 1 when c == c_lu)
+__device__ __forceinline__ double correction_scale(double c, double c_lu) {
+#if SMC_K8_POLICY
+    return 2.0 / (1.0 + c_lu / c);
+#else
+    return 1.0;
+#endif
+}
+// IDA's convergence test after Newton iteration kk (0-based) with correction norm dy_norm: 1 converged, -1 failed, 0 go on
+__device__ __forceinline__ int newton_verdict_ida(int kk, double dy_norm, double &first, double &ss) {
+    if (kk == 0) {
+        first = dy_norm;
+        if (dy_norm <= 1e-4 * kEpcon) return 1;
+    } else {
+        const double q = dy_norm / first;
+        const double rate = (kk == 1) ? q : (kk == 2) ? sqrt(q) : cbrt(q);
+        if (!(rate <= kRateMax)) return -1;
+        ss = rate / (1.0 - rate);
+    }
+    return (ss * dy_norm <= kEpcon) ? 1 : 0;
+}
+
 // reciprocal of a wave-uniform value: v_rcp_f64 (2^-24) + one Newton step (2^-48: the iteration matrix of a
 // modified Newton method needs no more)
 __device__ __forceinline__ double recip1(double a) {
@@ -557,7 +611,7 @@ struct ElemBackward {
 
 // one modified-Newton iteration; returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
 __device__ __forceinline__ double elem_newton_iteration(int lane, double *lds, double *y, double *dd, const double *yp,
-                                                        const double *psi, const double *p, double c, double rtol,
+                                                        const double *psi, const double *p, double c, double corr, double rtol,
                                                         double atol, const double (&X)[kNX], const double (&G)[kNX],
                                                         DaeStats &st) {
     SMC_PROF_BEGIN();
@@ -598,7 +652,11 @@ __device__ __forceinline__ double elem_newton_iteration(int lane, double *lds, d
     if (node)
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) {
+#if SMC_K8_POLICY
+            const double dx = z[lane * kZRow + f] * corr;      // matrix of another cj: 2 / (1 + cjratio)
+#else
             const double dx = z[lane * kZRow + f];
+#endif
             const double sc = atol + rtol * fabs(yp[f]);
             // weights of a convergence norm: the reciprocal with two Newton steps (~1 ulp) instead of the IEEE division's
             // scaling / fix-up sequence (13 instructions per component and iteration; sc is within [atol, atol + rtol |y|])
@@ -660,7 +718,8 @@ __device__ __forceinline__ void elem_change_D(const DViewE &D, int order, double
 // row 0 of the differences array and zeros in rows 1..7 on entry; the state at tf is left in row 0.
 __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const double *p, double tf, double rtol,
                                                    double atol, double h0, int max_attempts, DaeStats &st) {
-    const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+    const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));   // SMC_K8_POLICY 0 only
+    (void)newton_tol;
     const bool node = lane < kNX;
     const DViewE D{lds + kLdsD, lane};
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
@@ -674,6 +733,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
     double X[kNX], G[kNX];
     bool lu_valid = false, force_rebuild = false;
     double c_lu = 0.0;
+    double ss = kSsAfterSetup, c_last = 0.0;   // SMC_K8_POLICY 1: the carried convergence-rate factor, c of the previous attempt
     double yp[7], y[7], psi[7], dd[7];
     for (;;) {  // one iteration = one step attempt
         // The state that steers the attempt, pinned to scalars (meth_dae_wave.h: wave_uniform): the values are equal in all
@@ -681,6 +741,10 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
         t = wave_uniform(t);
         h_abs = wave_uniform(h_abs);
         c_lu = wave_uniform(c_lu);
+#if SMC_K8_POLICY
+        ss = wave_uniform(ss);
+        c_last = wave_uniform(c_last);
+#endif
         order = __builtin_amdgcn_readfirstlane(order);
         n_equal = __builtin_amdgcn_readfirstlane(n_equal);
         attempts = __builtin_amdgcn_readfirstlane(attempts);
@@ -724,28 +788,47 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
                 dd[f] = 0.0;
             }
         }
-        // The factored iteration matrix is kept while c = h/alpha_k is unchanged; rebuilt at the current predictor when
-        // c changed, or - by repeating this attempt - when Newton stalled on a stale matrix (bdf.py:343-357).
-        // (Not applying growth factors below 1.5, as CVODE does, cut the factorisations to 79 per solve but cost 9 % more
-        // steps: no gain.  IDA's policy of also keeping it while c drifts by < 25 %, with the correction scaled by 2/(1+cjratio), cut the
-        // factorisations from 100 to 63 per solve but raised the Newton iterations from 720 to 913: slower in total.)
-        const bool fresh = !lu_valid || c != c_lu || force_rebuild;
+        // The factored iteration matrix is kept while it is not stale (matrix_is_stale: policy 1 - cj within (0.6, 1.67) of the
+        // cj it was evaluated with; policy 0 - c unchanged, bdf.py:343-357); rebuilt at the current predictor otherwise, or - by
+        // repeating this attempt - when Newton failed on a kept matrix.
+        // (Rounds 2-4 tried the pieces of IDA's policy one at a time inside SciPy's control and dropped each: keeping the matrix
+        // while c drifts cut the factorisations but raised SciPy-test Newton iterations 720 -> 913; the carried rate alone cut
+        // the iterations 720 -> 435.  Together, with IDA's own convergence constant, they pay: oracle study, then the GPU A/B
+        // in profiles/r05_ab_k8_policy.log.)
+        const bool fresh = !lu_valid || force_rebuild || matrix_is_stale(c, c_lu);
+#if SMC_K8_POLICY
+        if (c != c_last) ss = kSsAfterCjChange;
+        c_last = c;
+#endif
         SMC_PROF_ADD(st, 6);
         if (fresh) {
             ++st.nlu;
             lu_valid = elem_build_and_factor(lane, lds, yp, psi, p, c, X, G, st);
             c_lu = c;
             force_rebuild = false;
+            ss = kSsAfterSetup;
         }
         bool converged = false;
         int n_iter = 0;
         if (lu_valid) {
-            // bdf.py:365-382.  (Carrying the convergence rate over from the previous step, as IDA and CVODE do, cut the
-            // Newton iterations from 720 to 435 per solve but moved single solves by > 200 tolerance units: not adopted.)
+            const double corr = wave_uniform(correction_scale(c, c_lu));
+#if SMC_K8_POLICY
+            double dy_first = 0.0;
+#pragma unroll 1
+            for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
+                const double dy_norm = elem_newton_iteration(lane, lds, y, dd, yp, psi, p, c, corr, rtol, atol, X, G, st);
+                n_iter = kk + 1;
+                ++st.newton_iters;
+                if (dy_norm < 0) break;
+                const int verdict = newton_verdict_ida(kk, dy_norm, dy_first, ss);
+                if (verdict != 0) { converged = verdict > 0; break; }
+            }
+#else
+            // bdf.py:365-382
             double dy_norm_old = -1.0;
 #pragma unroll 1
             for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
-                const double dy_norm = elem_newton_iteration(lane, lds, y, dd, yp, psi, p, c, rtol, atol, X, G, st);
+                const double dy_norm = elem_newton_iteration(lane, lds, y, dd, yp, psi, p, c, corr, rtol, atol, X, G, st);
                 n_iter = kk + 1;
                 ++st.newton_iters;
                 if (dy_norm < 0) break;
@@ -755,6 +838,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
                 if (dy_norm == 0 || (rate >= 0 && rate * scaled < newton_tol)) { converged = true; break; }
                 dy_norm_old = dy_norm;
             }
+#endif
         }
         SMC_PROF_ADD(st, 8);   // factorisation + Newton loop incl. control (slots 0,7,1,2,3 are inside)
         if (!converged && !fresh) {   // stale matrix: same step again with a fresh one

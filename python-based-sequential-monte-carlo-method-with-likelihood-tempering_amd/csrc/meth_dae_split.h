@@ -395,7 +395,7 @@ __device__ __forceinline__ void split_solve(int w, int lane_in, double *lds, con
 
 // one modified-Newton iteration (wave 0); returns RMS(dy/scale) over all unknowns, or -1 if the residual is not finite
 __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, double *y, double *dd, const double *psi,
-                                                         const double *p_in, double c, double rtol, double atol,
+                                                         const double *p_in, double c, double corr, double rtol, double atol,
                                                          const double (&X)[kMid + 1], const double (&G)[kMid], DaeStats &st) {
     SMC_PROF_BEGIN();
     const double cj = 1.0 / c;
@@ -427,7 +427,11 @@ __device__ __forceinline__ double split_newton_iteration(int lane, double *lds, 
     if (node)
         SMC_UNROLL
         for (int f = 0; f < 7; ++f) {
+#if SMC_K8_POLICY
+            const double dx = z[lane * kZRow + f] * corr;      // matrix of another cj: 2 / (1 + cjratio)
+#else
             const double dx = z[lane * kZRow + f];
+#endif
             const double sc = atol + rtol * fabs(y[f] - dd[f]);      // the predictor: y = yp + dd (kept as y and dd only - 14 VGPRs)
             const double q = dx * recip1(sc);
             sumsq += q * q;
@@ -463,7 +467,8 @@ __device__ __forceinline__ void dae_split_server(double *lds, int lane) {
 // left in row 0.  Time stepping, Newton control and error tests: meth_dae_elem.h (dae_elem_integrate), line by line.
 __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const double *p, double tf, double rtol, double atol,
                                                     double h0, int max_attempts, DaeStats &st) {
-    const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));
+    const double newton_tol = fmax(10 * 2.220446049250313e-16 / rtol, fmin(0.03, sqrt(rtol)));   // SMC_K8_POLICY 0 only
+    (void)newton_tol;
     const bool node = lane < kNX;
     const DViewE D{lds + kLdsD, lane};
     st.steps = st.rejects = st.newton_fail = st.nlu = st.newton_iters = 0;
@@ -477,11 +482,16 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
     double X[kMid + 1], G[kMid];
     bool lu_valid = false, force_rebuild = false;
     double c_lu = 0.0;
+    double ss = kSsAfterSetup, c_last = 0.0;   // SMC_K8_POLICY 1 (meth_dae_elem.h): carried convergence-rate factor, c of the previous attempt
     double y[7], psi[7], dd[7];
     for (;;) {  // one iteration = one step attempt
         t = wave_uniform(t);
         h_abs = wave_uniform(h_abs);
         c_lu = wave_uniform(c_lu);
+#if SMC_K8_POLICY
+        ss = wave_uniform(ss);
+        c_last = wave_uniform(c_last);
+#endif
         order = __builtin_amdgcn_readfirstlane(order);
         n_equal = __builtin_amdgcn_readfirstlane(n_equal);
         attempts = __builtin_amdgcn_readfirstlane(attempts);
@@ -525,7 +535,11 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
                 dd[f] = 0.0;
             }
         }
-        const bool fresh = !lu_valid || c != c_lu || force_rebuild;
+        const bool fresh = !lu_valid || force_rebuild || matrix_is_stale(c, c_lu);
+#if SMC_K8_POLICY
+        if (c != c_last) ss = kSsAfterCjChange;
+        c_last = c;
+#endif
         SMC_PROF_ADD(st, 6);   // predictor
         if (fresh) {
             ++st.nlu;
@@ -533,14 +547,28 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
             lu_valid = split_build_and_factor(0, lane, lds, y, psi, p, c, X, G, st);      // y is the predictor here
             c_lu = c;
             force_rebuild = false;
+            ss = kSsAfterSetup;
         }
         bool converged = false;
         int n_iter = 0;
         if (lu_valid) {
+            const double corr = wave_uniform(correction_scale(c, c_lu));
+#if SMC_K8_POLICY
+            double dy_first = 0.0;
+#pragma unroll 1
+            for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
+                const double dy_norm = split_newton_iteration(lane, lds, y, dd, psi, p, c, corr, rtol, atol, X, G, st);
+                n_iter = kk + 1;
+                ++st.newton_iters;
+                if (dy_norm < 0) break;
+                const int verdict = newton_verdict_ida(kk, dy_norm, dy_first, ss);
+                if (verdict != 0) { converged = verdict > 0; break; }
+            }
+#else
             double dy_norm_old = -1.0;
 #pragma unroll 1
             for (int kk = 0; kk < kNewtonMaxIter; ++kk) {
-                const double dy_norm = split_newton_iteration(lane, lds, y, dd, psi, p, c, rtol, atol, X, G, st);
+                const double dy_norm = split_newton_iteration(lane, lds, y, dd, psi, p, c, corr, rtol, atol, X, G, st);
                 n_iter = kk + 1;
                 ++st.newton_iters;
                 if (dy_norm < 0) break;
@@ -550,6 +578,7 @@ __device__ __forceinline__ void dae_split_integrate(double *lds, int lane, const
                 if (dy_norm == 0 || (rate >= 0 && rate * scaled < newton_tol)) { converged = true; break; }
                 dy_norm_old = dy_norm;
             }
+#endif
         }
         SMC_PROF_ADD(st, 8);   // factorisation + Newton loop incl. control
         if (!converged && !fresh) {   // stale matrix: same step again with a fresh one

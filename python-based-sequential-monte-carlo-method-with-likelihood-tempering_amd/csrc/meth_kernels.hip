@@ -135,8 +135,8 @@ dae_wave_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
             atomicAdd(&counters[1], (unsigned long long)st.rejects);
             atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
-#ifdef SMC_METH_PROFILE
             atomicAdd(&counters[4], (unsigned long long)st.nlu);
+#ifdef SMC_METH_PROFILE
             for (int q = 0; q < 12; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
 #endif
         }
@@ -182,8 +182,8 @@ dae_elem_kernel(const double *__restrict__ p0_all, const double *__restrict__ y0
             atomicAdd(&counters[1], (unsigned long long)st.rejects);
             atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
-#ifdef SMC_METH_PROFILE
             atomicAdd(&counters[4], (unsigned long long)st.nlu);
+#ifdef SMC_METH_PROFILE
             for (int q = 0; q < 12; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
 #endif
         }
@@ -238,8 +238,8 @@ dae_split_kernel(const double *__restrict__ p0_all, const double *__restrict__ y
             atomicAdd(&counters[1], (unsigned long long)st.rejects);
             atomicAdd(&counters[2], (unsigned long long)st.newton_fail);
             atomicAdd(&counters[3], (unsigned long long)st.newton_iters);
-#ifdef SMC_METH_PROFILE
             atomicAdd(&counters[4], (unsigned long long)st.nlu);
+#ifdef SMC_METH_PROFILE
             for (int q = 0; q < 12; ++q) atomicAdd(&counters[8 + q], (unsigned long long)st.prof[q]);
 #endif
         }
@@ -411,7 +411,7 @@ int smc_meth_dae_host(int device, const double *p0_all, const double *y0_all, in
         unsigned long long h[8];
         MH(hipMemcpy(h, dcnt, sizeof h, hipMemcpyDeviceToHost));
         if (stats)
-            for (int q = 0; q < 4; ++q) stats[q] = (int64_t)h[q];
+            for (int q = 0; q < 5; ++q) stats[q] = (int64_t)h[q];     // [4]: factorisations (0 from the debug kernels v1 / v2)
         if (!v1 && !v2 && (h[6] != (unsigned long long)n_solves || h[7] != 0)) {   // every solve exactly once, whole waves only
             g_meth_err = "dae_elem_kernel: " + std::to_string(h[6]) + " of " + std::to_string(n_solves) +
                          " solves finished, " + std::to_string(h[7]) + " waves split at a dequeue";

@@ -40,8 +40,10 @@ __device__ __forceinline__ double meth_loglike_step(double total, double c, doub
 // Any order gives the same results (the likelihood is always summed in index order); the order only decides how soon.
 __global__ void __launch_bounds__(256)
 meth_experiment_stats_kernel(const double *__restrict__ flows, const int *__restrict__ status, const uint8_t *__restrict__ p0mask,
-                             const double *__restrict__ obs, int64_t n, int n_data, double *__restrict__ stat /* 2 x n_data */) {
+                             const double *__restrict__ obs, int64_t n, int n_data, double *__restrict__ stat /* 2 x n_data */,
+                             const MHControl *__restrict__ ctl) {
     extern __shared__ double s_stat[];
+    if (ctl && ctl->stop) return;       // batch of iterations under device control: the loop has ended
     for (int i = threadIdx.x; i < 2 * n_data; i += blockDim.x) s_stat[i] = 0.0;
     __syncthreads();
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
@@ -62,9 +64,36 @@ meth_experiment_stats_kernel(const double *__restrict__ flows, const int *__rest
         if (s_stat[i] != 0.0) atomicAdd(&stat[i], s_stat[i]);
 }
 
-// the live proposals of an MH sweep, compacted (order irrelevant); queue[1] counts them
+// The order in which the NEXT sweep solves the experiments, on the device (rounds 2-4 read the statistics back and sorted on the
+// host: one synchronisation per sweep, which a batch of iterations under device control cannot afford): experiment e goes to
+// position #{e' : mean[e'] > mean[e], or equal and e' < e} - the stable descending sort of the means.  One block; then the
+// statistics are cleared for the sweep that is about to start.  Experiments without a solved item have mean 0.
+__global__ void __launch_bounds__(kWave)
+meth_order_kernel(double *__restrict__ stat /* 2 x n_data */, int n_data, int *__restrict__ order, const MHControl *__restrict__ ctl) {
+    __shared__ double s_mean[kWave];
+    if (ctl && ctl->stop) return;
+    const int e = threadIdx.x;
+    double mean = 0.0;
+    if (e < n_data) {
+        const double cnt = stat[n_data + e];
+        mean = cnt > 0 ? stat[e] / cnt : 0.0;
+        s_mean[e] = mean;
+    }
+    __syncthreads();
+    if (e < n_data) {
+        int pos = 0;
+        for (int q = 0; q < n_data; ++q) pos += (s_mean[q] > mean || (s_mean[q] == mean && q < e)) ? 1 : 0;
+        order[pos] = e;
+        stat[e] = 0.0;
+        stat[n_data + e] = 0.0;
+    }
+}
+
+// the live proposals of an MH sweep, compacted (order irrelevant); queue[1] counts them (ctl: none once the loop has ended - the
+// solve kernel then finds an empty list and leaves)
 __global__ void meth_livelist_kernel(const uint8_t *__restrict__ p0mask, int64_t n, int64_t *__restrict__ list,
-                                     unsigned long long *__restrict__ queue) {
+                                     unsigned long long *__restrict__ queue, const MHControl *__restrict__ ctl) {
+    if (ctl && ctl->stop) return;
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n || p0mask[p] == 0) return;   // masked proposal: lk2 == lk1, nothing to solve
     list[atomicAdd(&queue[1], 1ULL)] = p;   // one atomic per live lane: no cross-lane read follows, correct with or without the atomic optimiser
@@ -344,6 +373,9 @@ __global__ void meth_particle_loglike_kernel(MethModel m, const double *__restri
 __global__ void __launch_bounds__(256)
 generic_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt, int64_t stride, int64_t n, int d,
                        double *__restrict__ prop, int64_t pstride, uint8_t *__restrict__ p0_out) {
+    if (mh.ctl && mh.ctl->stop) return;      // batch of iterations under device control: the loop has ended
+    if (blockIdx.x == 0 && mh.zero_counters && threadIdx.x < sizeof(SweepCounters) / 8)   // (instead of a memset: that could not be skipped)
+        reinterpret_cast<unsigned long long *>(mh.zero_counters)[threadIdx.x] = 0ULL;
     if (blockIdx.x == 0 && threadIdx.x == 0 && mh.reject_out) {   // what the early-rejection bound of this sweep's solves reads
         RejectArgs r;
         r.lk1 = mh.reject_lk1;
@@ -384,9 +416,10 @@ generic_propose_kernel(Prior prior, MHParams mh, const double *__restrict__ filt
         for (int c = 0; c < d; ++c) z[c] = mh.noise[(int64_t)c * n + p];
     }
     double pdf = 1.0, cand[SMC_MAX_DIM], cur[SMC_MAX_DIM];
+    const double ratio = mh.ctl ? mh.ctl->ratio : mh.ratio;     // mhstep_ratio: the control kernel's under device control
     for (int c = 0; c < d; ++c) {
         cur[c] = filt[c * stride + p];
-        cand[c] = __dadd_rn(cur[c], __dmul_rn(z[c], mh.ratio));
+        cand[c] = __dadd_rn(cur[c], __dmul_rn(z[c], ratio));
         const double q = prior_pdf(prior.kind[c], prior.a[c], prior.b[c], cand[c]);
         pdf = (c == 0) ? q : pdf * q;
     }
@@ -410,6 +443,7 @@ generic_accept_kernel(MHParams mh, const double *__restrict__ prop, int64_t pstr
                       int64_t fstride, uint8_t *__restrict__ r_ac, SweepCounters *__restrict__ counters,
                       double *__restrict__ dbg_lk2, uint8_t *__restrict__ dbg_r) {
     __shared__ unsigned long long s_cnt[4][2];
+    if (mh.ctl && mh.ctl->stop) return;   // after the loop's `break`: p_filt, lk1, r_ac and the counters stay as they are
     unsigned long long acc_now = 0, acc_ever = 0;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
         const bool masked = p0_in[p] == 0;
@@ -458,7 +492,8 @@ generic_accept_kernel(MHParams mh, const double *__restrict__ prop, int64_t pstr
     }
 }
 
-static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask, bool reject) {
+static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, const uint8_t *p0mask, bool reject,
+                          const MHControl *ctl = nullptr) {
     const MethModel &m = ctx->meth;
     int64_t nwaves = (int64_t)ctx->cu_count * 4;
     if (nwaves > n * m.n_data) nwaves = n * m.n_data;
@@ -475,29 +510,15 @@ static void launch_solves(smc_ctx *ctx, const double *theta, int64_t stride, int
     const int64_t *live = nullptr;
     if (p0mask) {
         hipLaunchKernelGGL(meth_livelist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, p0mask, n,
-                           ctx->d_mwork, ctx->d_queue);
+                           ctx->d_mwork, ctx->d_queue, ctl);
         live = ctx->d_mwork;
     }
     const int *order = nullptr;
-    if (reject && ctx->stiff_first && ctx->d_morder) {
-        if (ctx->mstat_pending) {   // the misfit statistics the previous Metropolis sweep left behind -> this sweep's order
-            std::vector<double> st(2 * (size_t)m.n_data);
-            if (hipMemcpyAsync(st.data(), ctx->d_mstat, st.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
-                hipStreamSynchronize(ctx->stream) == hipSuccess) {
-                std::vector<int> ord(m.n_data);
-                for (int e = 0; e < m.n_data; ++e) ord[e] = e;
-                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
-                    const double ma = st[m.n_data + a] > 0 ? st[a] / st[m.n_data + a] : 0.0;
-                    const double mb = st[m.n_data + b] > 0 ? st[b] / st[m.n_data + b] : 0.0;
-                    return ma > mb;
-                });
-                (void)hipMemcpyAsync(ctx->d_morder, ord.data(), ord.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
-                (void)hipStreamSynchronize(ctx->stream);   // ord is a local
-                ctx->morder_valid = true;
-            }
-            ctx->mstat_pending = false;
-        }
-        if (ctx->morder_valid) order = ctx->d_morder;
+    if (reject && ctx->stiff_first && ctx->d_morder && m.n_data <= kWave) {
+        // the misfit statistics the previous Metropolis sweep left behind -> this sweep's order (all zero before the first
+        // sweep: the index order); meth_order_kernel clears them for this sweep's own statistics
+        hipLaunchKernelGGL(meth_order_kernel, dim3(1), dim3(kWave), 0, ctx->stream, ctx->d_mstat, m.n_data, ctx->d_morder, ctl);
+        order = ctx->d_morder;
     }
     if (meth_split_enabled())   // two waves per solve: the same number of workgroups (four solves per CU), twice the waves
         hipLaunchKernelGGL(meth_particles_dae_split_kernel, dim3((unsigned)nwaves), dim3(meth::kSplitThreads),
@@ -547,15 +568,13 @@ void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh_in) {
         mh.reject_lk1 = ctx->set[SMC_SET_FILT].lk;
     }
     launch_generic_propose(ctx, n, mh);
-    launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0, reject);
+    launch_solves(ctx, P.theta, P.stride, n, ctx->d_p0, reject, mh.ctl);
     if (ctx->launch_failed) return;
-    if (reject && ctx->stiff_first && ctx->d_mstat) {   // misfit per experiment of THIS sweep's proposals: the next sweep's order
-        (void)hipMemsetAsync(ctx->d_mstat, 0, 2 * (size_t)ctx->meth.n_data * sizeof(double), ctx->stream);
+    if (reject && ctx->stiff_first && ctx->d_mstat && ctx->meth.n_data <= kWave) {   // misfit per experiment of THIS sweep's proposals: the next sweep's order
         const int64_t g = (n + 255) / 256;
         hipLaunchKernelGGL(meth_experiment_stats_kernel, dim3((unsigned)(g < 512 ? g : 512)), dim3(256),
                            2 * (size_t)ctx->meth.n_data * sizeof(double), ctx->stream, ctx->d_mflows, ctx->d_mstatus, ctx->d_p0,
-                           ctx->meth.obs, n, ctx->meth.n_data, ctx->d_mstat);
-        ctx->mstat_pending = true;
+                           ctx->meth.obs, n, ctx->meth.n_data, ctx->d_mstat, mh.ctl);
     }
     hipLaunchKernelGGL(meth_particle_loglike_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->meth,
                        P.theta, P.stride, n, ctx->d_mflows, ctx->d_mstatus, ctx->d_p0, ctx->d_counters, ctx->d_mlk2);

@@ -7,7 +7,10 @@
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "exchange_plan.h"
@@ -92,6 +95,72 @@ static void timing_collect(smc_ctx *c) {
 }
 
 static int ensure_item_capacity(smc_ctx *c, int64_t n);
+
+// ---- collectives among local peers (debug API; rehearsal of the RCCL paths on one device) ------------------------------------
+// Contexts of one process on one device, one host thread each (tests/_thread_comm.py).  A collective = every rank copies its
+// words into its own contribution slot and records an event; the threads meet at a host barrier (all events recorded); every
+// rank makes its stream wait for the peers' events and runs ONE small kernel that reads all contributions in rank order.  Two
+// slots used alternately: a rank can only write slot s again after its own next collective, which needed every peer's
+// contribution to it, which a peer enqueues after its reads of slot s - so no second barrier.
+namespace {
+constexpr int kPeerWords = 2048, kPeerMax = 8;
+struct PeerBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int count = 0;
+    unsigned long gen = 0;
+};
+struct PeerPtrs { const double *p[kPeerMax]; };
+__global__ void peer_reduce_kernel(PeerPtrs src, int world, int n, double *out, int is_max) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        double v = src.p[0][i];
+        for (int q = 1; q < world; ++q) v = is_max ? fmax(v, src.p[q][i]) : v + src.p[q][i];   // rank order: the same on every rank
+        out[i] = v;
+    }
+}
+__global__ void peer_gather_kernel(PeerPtrs src, int world, int n, double *out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * world; i += gridDim.x * blockDim.x) out[i] = src.p[i / n][i % n];
+}
+}  // namespace
+static int peer_host_barrier(smc_ctx *c) {
+    PeerBarrier &b = *static_cast<PeerBarrier *>(c->peers[0]->peer_barrier);
+    std::unique_lock<std::mutex> lk(b.m);
+    const unsigned long g = b.gen;
+    if (++b.count == c->world) {
+        b.count = 0;
+        ++b.gen;
+        b.cv.notify_all();
+        return 0;
+    }
+    if (!b.cv.wait_for(lk, std::chrono::seconds(120), [&] { return b.gen != g; }))
+        return fail(c, "local-peer collective: a peer did not arrive within 120 s (the ranks disagree on a collective)");
+    return 0;
+}
+// in place over `n` doubles at buf (device): SUM or MAX over the peers
+static int peer_allreduce(smc_ctx *c, double *buf, size_t n, bool is_max, bool gather, double *gather_out) {
+    if (n * (gather ? 1 : 1) > (size_t)kPeerWords || (gather && n * c->world > (size_t)kPeerWords)) return fail(c, "local-peer collective: payload too large");
+    const int s = c->peer_parity;
+    c->peer_parity ^= 1;
+    double *slot = c->d_peer_contrib + (size_t)s * kPeerWords;
+    HIPC(c, hipMemcpyAsync(slot, buf, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIPC(c, hipEventRecord(c->peer_ev[s], c->stream));
+    if (peer_host_barrier(c)) return 1;
+    PeerPtrs src{};
+    for (int q = 0; q < c->world; ++q) {
+        src.p[q] = c->peers[q]->d_peer_contrib + (size_t)s * kPeerWords;
+        if (q != c->rank) HIPC(c, hipStreamWaitEvent(c->stream, c->peers[q]->peer_ev[s], 0));
+    }
+    if (gather)
+        hipLaunchKernelGGL(peer_gather_kernel, dim3(1), dim3(256), 0, c->stream, src, c->world, (int)n, gather_out);
+    else
+        hipLaunchKernelGGL(peer_reduce_kernel, dim3(1), dim3(256), 0, c->stream, src, c->world, (int)n, buf, is_max ? 1 : 0);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+static bool peers_on(const smc_ctx *c) { return c->peer_collectives && c->world > 1 && !c->peers.empty(); }
+// does a *_global entry point have ranks to reduce over, and the means to?  (RCCL, or the local peers of a rehearsal)
+static bool can_reduce(const smc_ctx *c) { return c->nccl_comm != nullptr || peers_on(c); }
+static int peer_exchange(smc_ctx *c);
 
 extern "C" {
 
@@ -259,6 +328,12 @@ void smc_destroy(smc_ctx *c) {
     (void)hipFree(c->d_hb_theta);
     (void)hipFree(c->d_hb_lk);
     (void)hipFree(c->d_hb_pred);
+    (void)hipFree(c->d_peer_contrib);
+    for (int s = 0; s < 2; ++s)
+        if (c->peer_ev[s]) (void)hipEventDestroy(c->peer_ev[s]);
+    if (c->peer_pack_ev) (void)hipEventDestroy(c->peer_pack_ev);
+    if (c->peer_pull_ev) (void)hipEventDestroy(c->peer_pull_ev);
+    delete static_cast<PeerBarrier *>(c->peer_barrier);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -720,6 +795,10 @@ int smc_ess_partials(smc_ctx *c, double max_lk, const double *gm, int n_cand, do
 }  // extern "C"
 static int dev_allreduce(smc_ctx *c, void *buf, size_t n, ncclDataType_t dt, ncclRedOp_t op) {
     if (!c->nccl_comm) {
+        if (peers_on(c)) {
+            if (dt != ncclDouble || (op != ncclSum && op != ncclMax)) return fail(c, "local-peer collective: only SUM / MAX of doubles");
+            return peer_allreduce(c, static_cast<double *>(buf), n, op == ncclMax, false, nullptr);
+        }
         if (c->world > 1) return fail(c, "world > 1 but smc_comm_init has not been called (the *_global entry points need RCCL)");
         return 0;
     }
@@ -729,7 +808,10 @@ static int dev_allreduce(smc_ctx *c, void *buf, size_t n, ncclDataType_t dt, ncc
 // all-gather of n 8-byte words per rank from d_small[0..n) into d_small[2048 ..), then to h_small[0 .. n*world)
 static int dev_allgather_words(smc_ctx *c, int n) {
     if ((size_t)n * c->world > 2048) return fail(c, "collective payload too large");
-    if (!c->nccl_comm) {
+    if (!c->nccl_comm && peers_on(c)) {
+        if (peer_allreduce(c, c->d_small, (size_t)n, false, true, c->d_small + 2048)) return 1;
+        HIPC(c, hipMemcpyAsync(c->h_small, c->d_small + 2048, (size_t)n * c->world * 8, hipMemcpyDeviceToHost, c->stream));
+    } else if (!c->nccl_comm) {
         if (c->world > 1) return fail(c, "world > 1 but smc_comm_init has not been called (the *_global entry points need RCCL)");
         HIPC(c, hipMemcpyAsync(c->h_small, c->d_small, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     } else {
@@ -1069,6 +1151,39 @@ int smc_exchange_plan(int world, int rank, int64_t n_local, const int64_t *out_b
     return 0;
 }
 
+// the copies of smc_resample_phase3_pull, enqueued (peers' blocks -> this rank's FILT rows)
+static int peer_pull_copies(smc_ctx *c) {
+    const int W = c->world, R = c->rank, d = c->dim;
+    const int64_t nl = c->n_local;
+    ParticleSet &F = c->set[SMC_SET_FILT];
+    for (int q = 0; q < W; ++q) {
+        if (q == R) continue;
+        smc_ctx *src = c->peers[q];
+        const int64_t lo = imax(c->plan_base[q], R * nl), hi = imin(c->plan_base[q] + c->plan_cnt[q], (R + 1) * nl);
+        if (hi <= lo) continue;
+        const int64_t off = lo - R * nl, cnt = hi - lo;
+        if (src->plan_send_cnt[R] != cnt) return fail(c, "loopback exchange: sender and receiver disagree on a count");
+        const double *blk = src->d_sendbuf + (size_t)src->plan_send_off[R] * (d + 1);
+        for (int k = 0; k < d; ++k)
+            HIPC(c, hipMemcpyAsync(F.theta + (size_t)k * F.stride + off, blk + (size_t)k * cnt, (size_t)cnt * sizeof(double),
+                                   hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(F.lk + off, blk + (size_t)d * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice,
+                               c->stream));
+    }
+    return 0;
+}
+// step 3 of smc_resample_phase3 among local peers with the collectives inside the engine: packed | barrier | pull | barrier
+static int peer_exchange(smc_ctx *c) {
+    HIPC(c, hipEventRecord(c->peer_pack_ev, c->stream));
+    if (peer_host_barrier(c)) return 1;            // every rank has packed (recorded) and published its plan
+    for (int q = 0; q < c->world; ++q)
+        if (q != c->rank) HIPC(c, hipStreamWaitEvent(c->stream, c->peers[q]->peer_pack_ev, 0));
+    if (peer_pull_copies(c)) return 1;
+    HIPC(c, hipEventRecord(c->peer_pull_ev, c->stream));
+    c->peer_pull_recorded = true;
+    return peer_host_barrier(c);                   // nobody packs again before every pull is at least enqueued and recorded
+}
+
 int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *offspring_all, int first_step) {
     if (!c) return fail(nullptr, "NULL context");
     HIPC(c, hipSetDevice(c->device));
@@ -1083,6 +1198,9 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
                        "Micmem_SMC_main.py:180)");
     ScopedTimer tm(c, SMC_T_RESAMPLE);
 
+    if (W > 1 && peers_on(c))                 // the peers' pulls out of this rank's send staging at the previous exchange must be
+        for (int q = 0; q < W; ++q)           // over before it is packed (or reallocated) again
+            if (q != R && c->peers[q]->peer_pull_recorded) HIPC(c, hipStreamWaitEvent(c->stream, c->peers[q]->peer_pull_ev, 0));
     if (plan.send_total > c->sendbuf_cap) {   // how much leaves this rank
         HIPC(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->d_sendbuf);
@@ -1109,6 +1227,7 @@ int smc_resample_phase3(smc_ctx *c, const int64_t *out_base_all, const int64_t *
     c->plan_send_cnt = plan.send_cnt;
     c->plan_base.assign(out_base_all, out_base_all + W);
     c->plan_cnt.assign(offspring_all, offspring_all + W);
+    if (W > 1 && peers_on(c) && !c->nccl_comm) return peer_exchange(c);   // rehearsal with the collectives inside the engine
     if (W > 1 && !c->peers.empty()) {  // loopback rehearsal: the pull happens after a barrier between the ranks
         HIPC(c, hipStreamSynchronize(c->stream));
         return 0;
@@ -1130,28 +1249,29 @@ int smc_debug_set_local_peers(smc_ctx *c, smc_ctx **peers, int rank, int world) 
     return 0;
 }
 
+int smc_debug_peer_collectives(smc_ctx *c, int enable) {
+    if (!c) return fail(nullptr, "NULL context");
+    if (c->peers.empty()) return fail(c, "smc_debug_set_local_peers has not been called");
+    if (c->world > kPeerMax) return fail(c, "in-engine collectives among local peers: at most 8 ranks");
+    HIPC(c, hipSetDevice(c->device));
+    if (enable && !c->d_peer_contrib) {
+        HIPC(c, hipMalloc(&c->d_peer_contrib, 2 * (size_t)kPeerWords * sizeof(double)));
+        for (int s = 0; s < 2; ++s) HIPC(c, hipEventCreateWithFlags(&c->peer_ev[s], hipEventDisableTiming));
+        HIPC(c, hipEventCreateWithFlags(&c->peer_pack_ev, hipEventDisableTiming));
+        HIPC(c, hipEventCreateWithFlags(&c->peer_pull_ev, hipEventDisableTiming));
+        c->peer_barrier = new (std::nothrow) PeerBarrier();
+        if (!c->peer_barrier) return fail(c, "out of memory");
+    }
+    c->peer_collectives = enable != 0;
+    return 0;
+}
+
 int smc_resample_phase3_pull(smc_ctx *c) {
     if (!c) return fail(nullptr, "NULL context");
     if (c->peers.empty()) return fail(c, "smc_debug_set_local_peers has not been called");
     HIPC(c, hipSetDevice(c->device));
     c->moments_valid = false;   // the FILT set changes: carried moments no longer describe it
-    const int W = c->world, R = c->rank, d = c->dim;
-    const int64_t nl = c->n_local;
-    ParticleSet &F = c->set[SMC_SET_FILT];
-    for (int q = 0; q < W; ++q) {
-        if (q == R) continue;
-        smc_ctx *src = c->peers[q];
-        const int64_t lo = imax(c->plan_base[q], R * nl), hi = imin(c->plan_base[q] + c->plan_cnt[q], (R + 1) * nl);
-        if (hi <= lo) continue;
-        const int64_t off = lo - R * nl, cnt = hi - lo;
-        if (src->plan_send_cnt[R] != cnt) return fail(c, "loopback exchange: sender and receiver disagree on a count");
-        const double *blk = src->d_sendbuf + (size_t)src->plan_send_off[R] * (d + 1);
-        for (int k = 0; k < d; ++k)
-            HIPC(c, hipMemcpyAsync(F.theta + (size_t)k * F.stride + off, blk + (size_t)k * cnt, (size_t)cnt * sizeof(double),
-                                   hipMemcpyDeviceToDevice, c->stream));
-        HIPC(c, hipMemcpyAsync(F.lk + off, blk + (size_t)d * cnt, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice,
-                               c->stream));
-    }
+    if (peer_pull_copies(c)) return 1;
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1361,10 +1481,10 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
     if (c->model_kind != 1) return fail(c, "smc_mh_sweeps_device_rng: Michaelis-Menten model only (the other models take smc_mh_iteration_device_rng)");
     if (!w_cov) return fail(c, "smc_mh_sweeps_device_rng: w_cov is NULL");
     if (n_iter < 1 || n_iter > kMHBatchMax) return fail(c, "smc_mh_sweeps_device_rng: n_iter must be 1 .. 32");
-    if (c->world > 1 && !c->nccl_comm) return fail(c, "world > 1 but smc_comm_init has not been called (the batch needs RCCL)");
+    if (c->world > 1 && !can_reduce(c)) return fail(c, "world > 1 but smc_comm_init has not been called (the batch needs RCCL)");
     HIPC(c, hipSetDevice(c->device));
     const int d = c->dim, nv = d + d * (d + 1) / 2;
-    const bool one_rank = c->nccl_comm == nullptr;
+    const bool one_rank = !can_reduce(c);      // a one-rank RCCL communicator (tests) takes the several-ranks path as well
     double *S = c->d_fused;
     MHControlArgs a{};
     a.ctl = c->d_mhctl;
@@ -1380,6 +1500,15 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
     a.cov_out = S + kCov;
     a.xform_out = S + kXf;
     const int parity0 = c->stiff_parity;
+    // a failure in the middle of the batch (a launch, a collective): what is already enqueued drains, and the list parity goes
+    // back to where the batch found it - the counters of lists that were never consumed are cleared by the next builder anyway,
+    // but a caller that goes on after the error must not find the parity toggled an unknown number of times
+    auto bail = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        c->stiff_parity = parity0;
+        c->moments_valid = false;
+        return 1;
+    };
     ScopedTimer tm_mh(c, SMC_T_MH);
     {   // the first iteration's factor: carried moments, or np.cov's two-pass route when the FILT set changed since
         ScopedTimer tm(c, SMC_T_MOMENTS);
@@ -1390,9 +1519,9 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
             a.sums = nullptr;
         } else {
             launch_moment_sums(c, S + kSums);
-            if (dev_allreduce(c, S + kSums, (size_t)d, ncclDouble, ncclSum)) return 1;
+            if (dev_allreduce(c, S + kSums, (size_t)d, ncclDouble, ncclSum)) return bail();
             launch_moment_centered_dev(c, S + kSums, S + kCent);
-            if (dev_allreduce(c, S + kCent, (size_t)(d * (d + 1) / 2), ncclDouble, ncclSum)) return 1;
+            if (dev_allreduce(c, S + kCent, (size_t)(d * (d + 1) / 2), ncclDouble, ncclSum)) return bail();
             a.mom = S + kCent;
             a.sums = S + kSums;
         }
@@ -1416,11 +1545,11 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
         mh.moment_rows = c->d_partials;
         mh.ctl = c->d_mhctl;
         launch_mm_mh(c, c->n_local, mh);
-        HIPC(c, hipGetLastError());
-        if (c->launch_failed) { c->launch_failed = false; return 1; }
+        if (hipGetLastError() != hipSuccess) { fail(c, "smc_mh_sweeps_device_rng: a kernel launch of the batch failed"); return bail(); }
+        if (c->launch_failed) { c->launch_failed = false; return bail(); }
         if (!one_rank) {
             launch_moments_reduce(c, c->moment_rows_n, nv, S + kV, c->d_mhctl);
-            if (dev_allreduce(c, S + kV, (size_t)nv + 3, ncclDouble, ncclSum)) return 1;
+            if (dev_allreduce(c, S + kV, (size_t)nv + 3, ncclDouble, ncclSum)) return bail();
         }
         ScopedTimer tm(c, SMC_T_MOMENTS);
         a.mode = kCtlDecide | (i + 1 < n_iter ? kCtlTransform : 0);

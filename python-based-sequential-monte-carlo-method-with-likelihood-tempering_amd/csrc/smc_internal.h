@@ -65,6 +65,18 @@ struct StiffList {
     unsigned solo_cap;          // solo entries this sweep's grid can run at once (one per wave): the rest join the ordinary list
 };
 
+struct SweepCounters {  // device-side integer counters (order-independent atomics)
+    unsigned long long n_failed, rk_attempts, accepted_now, accepted_ever;
+    unsigned long long newton_iters, factorisations, failed_solves;   // K8 only (methanation)
+    // K8 sweep bookkeeping: solves the DAE kernel was asked for / finished, live items the likelihood kernel found
+    // unsolved (status still poisoned), waves that were incomplete at a dequeue.  A sweep is valid only if
+    // completed == expected and the other two are zero (checked on the host after every sweep).
+    unsigned long long expected_solves, completed_solves, unsolved_items, wave_split;
+    unsigned long long cancelled_solves;   // solves not started because their proposal was already certain to be rejected
+    unsigned long long long_items;         // Michaelis-Menten: items that needed more than kLongItemAttempts attempts (mm_kernels.hip)
+    unsigned long long solved_items;       // Michaelis-Menten: (particle, experiment) solves that reached t_bound and produced their dense outputs
+};
+
 // Loop control of a batch of Metropolis iterations on the device (stage_kernels.hip: mh_control_kernel;
 // Micmem_SMC_main.py:243-249).  One block in device memory per context; every kernel of an iteration that belongs to a batch
 // reads `stop` first thing and returns at once when it is set.
@@ -79,6 +91,8 @@ struct MHLogEntry {             // what the driver's Python kept per iteration (
     double accepted_now, accepted_ever, n_failed;   // totals over all ranks
     unsigned long long rk_attempts, long_items;     // this rank's
     unsigned long long solved_items;                // this rank's: solves of the iteration that ran to the end (not cancelled, not masked)
+    SweepCounters snap;                             // this rank's counters as the iteration left them (methanation: K8's work and the
+                                                    // completeness bookkeeping the host checks per sweep)
     double cov[SMC_MAX_DIM * SMC_MAX_DIM];          // cov_m of the iteration (:212-215)
 };
 constexpr int kMHBatchMax = 32;                     // iterations per batch (ad_mhstep_num is 20)
@@ -93,6 +107,7 @@ struct MHControlArgs {
     // DECIDE
     const double *rows;         // one rank: per-block moment rows of the accept kernel (nullptr: vec is already reduced)
     int n_rows, nv;
+    int counts_local;           // one rank, no rows (models without carried moments): the counts come straight from `counters`
     double *vec;                // [moments (nv) | accepted_now, accepted_ever, n_failed]
     const SweepCounters *counters;
     // TRANSFORM (mh_transform_body)
@@ -133,17 +148,6 @@ struct MHParams {    // passed by value to the fused MH kernel
     int *done_info;
 };
 
-struct SweepCounters {  // device-side integer counters (order-independent atomics)
-    unsigned long long n_failed, rk_attempts, accepted_now, accepted_ever;
-    unsigned long long newton_iters, factorisations, failed_solves;   // K8 only (methanation)
-    // K8 sweep bookkeeping: solves the DAE kernel was asked for / finished, live items the likelihood kernel found
-    // unsolved (status still poisoned), waves that were incomplete at a dequeue.  A sweep is valid only if
-    // completed == expected and the other two are zero (checked on the host after every sweep).
-    unsigned long long expected_solves, completed_solves, unsolved_items, wave_split;
-    unsigned long long cancelled_solves;   // solves not started because their proposal was already certain to be rejected
-    unsigned long long long_items;         // Michaelis-Menten: items that needed more than kLongItemAttempts attempts (mm_kernels.hip)
-    unsigned long long solved_items;       // Michaelis-Menten: (particle, experiment) solves that reached t_bound and produced their dense outputs
-};
 
 struct EventPair {
     hipEvent_t a, b;
@@ -253,6 +257,16 @@ struct smc_ctx {
     // loopback rehearsal (smc_debug_set_local_peers): peer contexts on the same device, last exchange plan
     std::vector<smc_ctx *> peers;
     std::vector<int64_t> plan_send_off, plan_send_cnt, plan_base, plan_cnt;
+    // ... with the collectives INSIDE the engine (smc_debug_peer_collectives): every ncclAllReduce / ncclAllGather / send-recv of
+    // the *_global entry points replaced by its counterpart among the peer contexts - events between their streams, a host
+    // barrier between their threads - so that the world > 1 branches of those entry points run on a one-GPU box
+    bool peer_collectives = false;
+    double *d_peer_contrib = nullptr;           // 2 x kPeerWords: this rank's contribution to a collective, two in turn
+    hipEvent_t peer_ev[2]{};                    // ... recorded once it is written
+    hipEvent_t peer_pack_ev = nullptr, peer_pull_ev = nullptr;   // exchange: send staging packed / peers' blocks pulled
+    bool peer_pull_recorded = false;
+    int peer_parity = 0;
+    void *peer_barrier = nullptr;               // host barrier of the peer threads (rank 0's object is the one in use)
 
     // timing
     int timing = 0;
@@ -278,7 +292,7 @@ const unsigned *cost_n_ordered(const smc_ctx *ctx);   // ... and where the solve
 const unsigned *launch_cost_sort_order(smc_ctx *ctx, int64_t n);   // mm_kernels.hip: counting sort of ctx->d_bucket into ctx->d_order
 // implemented in meth_smc.hip
 void launch_meth_loglik(smc_ctx *ctx, const double *theta, int64_t stride, int64_t n, double *lk);
-void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);
+void launch_meth_mh(smc_ctx *ctx, int64_t n, const MHParams &mh);   // mh.ctl set: every kernel of the sweep is a no-op once the loop has ended
 // any dimension: proposal + support mask into the PRED set / d_p0; accept-select from a per-particle lk2 array
 void launch_generic_propose(smc_ctx *ctx, int64_t n, const MHParams &mh);
 void launch_generic_accept(smc_ctx *ctx, int64_t n, const MHParams &mh, const double *lk2);

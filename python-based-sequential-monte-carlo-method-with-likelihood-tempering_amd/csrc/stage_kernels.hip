@@ -466,6 +466,10 @@ __global__ void __launch_bounds__(kScanBlock) mh_control_kernel(MHControlArgs a,
                 a.vec[a.nv + 1] = (double)a.counters->accepted_ever;
                 a.vec[a.nv + 2] = (double)a.counters->n_failed;
             }
+        } else if (a.counts_local && t == 0) {
+            a.vec[a.nv] = (double)a.counters->accepted_now;
+            a.vec[a.nv + 1] = (double)a.counters->accepted_ever;
+            a.vec[a.nv + 2] = (double)a.counters->n_failed;
         }
     }
     if (t != 0) return;
@@ -478,6 +482,7 @@ __global__ void __launch_bounds__(kScanBlock) mh_control_kernel(MHControlArgs a,
         e.rk_attempts = a.counters->rk_attempts;       // this rank's
         e.long_items = a.counters->long_items;
         e.solved_items = a.counters->solved_items;
+        e.snap = *a.counters;
         ctl->n_done = a.iteration;
         if (acc_ever > ctl->thr_stop || n_failed != 0.0) {
             ctl->stop = 1;

@@ -466,6 +466,13 @@ class HipEngine:
         self.rank, self.world = int(rank), len(engines)
         self._peer_barrier = barrier
 
+    def debug_peer_collectives(self, enable=True):
+        """Loopback rehearsal with the collectives inside the engine (include/smc_hip.h: smc_debug_peer_collectives): the
+        *_global entry points reduce among the local peers; the Python-side pull of resample_phase3 is no longer needed."""
+        self._ck(self.L.smc_debug_peer_collectives(self.ctx, int(bool(enable))), "smc_debug_peer_collectives")
+        if enable:
+            self._peer_barrier = None
+
     # ---- moments -------------------------------------------------------------------------------
     def moment_sums_local(self):
         out = np.empty(self.dim)

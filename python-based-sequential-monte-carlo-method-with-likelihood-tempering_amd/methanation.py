@@ -70,13 +70,13 @@ def dae_solve_batch(p0_all, y0_all, tf=75.0, rtol=1e-6, atol=1e-6, h0=1e-5, want
     flows = np.empty((n, 5))
     status = np.empty(n, dtype=np.int32)
     states = np.empty((n, NSTATE)) if want_states else None
-    stats = np.zeros(4, dtype=np.int64)
+    stats = np.zeros(5, dtype=np.int64)
     ms = B.ctypes.c_double(0)
     _ck(lib().smc_meth_dae_host(device, _dp(p0_all), _dp(y0_all), n, tf, rtol, atol, h0, S_AREA, P_STP, _dp(flows),
                                 _dp(states) if want_states else None, status.ctypes.data_as(B.ctypes.POINTER(B.ctypes.c_int32)),
                                 stats.ctypes.data_as(B.c_i64p), B.ctypes.byref(ms)), "smc_meth_dae_host")
     info = {"steps": int(stats[0]), "rejects": int(stats[1]), "newton_fail": int(stats[2]), "newton_iters": int(stats[3]),
-            "kernel_ms": ms.value}
+            "factorisations": int(stats[4]), "kernel_ms": ms.value}
     return flows, status, states, info
 
 

@@ -239,8 +239,10 @@ def test_methanation_loglik_sweep_and_mh_step_vs_oracle(pkg, M, cond_guess):
         assert info["rk_attempts"] > 150 * n * 30
         k8 = eng.meth_sweep_counters()                                       # device-counted work of that sweep
         assert k8["bdf_steps"] == info["rk_attempts"] and k8["failed_solves"] == 0
-        assert 2 * k8["bdf_steps"] <= k8["newton_iters"] < 4 * k8["bdf_steps"]     # bdf.py needs >= 2 iterations per step
-        assert 0.1 * k8["bdf_steps"] < k8["factorisations"] < k8["bdf_steps"]
+        # round 5, IDA's control policy (csrc/meth_dae_elem.h: SMC_K8_POLICY 1): the carried convergence rate lets most steps
+        # converge in ONE Newton iteration (bdf.py needed >= 2), the matrix survives a drift of cj (one factorisation per 5-8 steps)
+        assert k8["bdf_steps"] <= k8["newton_iters"] < 3 * k8["bdf_steps"]
+        assert 0.03 * k8["bdf_steps"] < k8["factorisations"] < 0.5 * k8["bdf_steps"]
         # one MH iteration with host-drawn noise; proposals 2 and 4 are pushed out of the prior box
         eng.set_debug_capture(True)
         eng.upload_lk(pkg.SMC_SET_FILT, lk)

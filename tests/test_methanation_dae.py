@@ -53,6 +53,27 @@ def test_tolerance_refinement_and_steady_state(M, setup, i):
     assert np.abs(r[1:50]).max() < 1e-3 * np.abs(M.reaction(guess[i], np.zeros(357), p)).max()
 
 
+@pytest.mark.parametrize("i", [0, 7, 19, 29])
+def test_k8_control_policy_against_the_checker(M, setup, i):
+    """Round 5: K8 follows IDA's policy for the iteration matrix and the Newton iteration (csrc/meth_dae_elem.h, SMC_K8_POLICY 1;
+    stated on the CPU by dae_policy {2, 1, 0, 0.33, 0.15}).  Same equations, same tolerances, same step-size control: the outlet
+    state stays within a few tolerance units of the checker's default policy (matrix at every attempt, SciPy's Newton test) and of
+    a 1e-9 run, with a fraction of the factorisations and fewer than two Newton iterations per attempt."""
+    cond, guess = setup
+    outlet = [50, 101, 152, 203, 254, 305, 356]
+    for pr in (M.BASEPARAMS, M.BASEPARAMS * np.array([3.0, 1.0, 0.3, 1.0, 1, 1, 1, 1])):
+        p = M.p0_tuple(cond, i, pr)
+        y_chk, rc0, st0 = M.dae_solve_policy(guess[i], p, None)
+        y_k8, rc1, st1 = M.dae_solve_policy(guess[i], p, M.k8_policy())
+        y_ref, rc2, _ = M.dae_solve_policy(guess[i], p, None, rtol=1e-9, atol=1e-9)
+        assert rc0 == rc1 == rc2 == 0
+        units = lambda a, b: np.max(np.abs(a - b)[outlet] / (1e-6 + 1e-6 * np.abs(b[outlet])))
+        assert units(y_k8, y_chk) < 5.0 and units(y_k8, y_ref) < 5.0 and units(y_chk, y_ref) < 5.0
+        assert st0["nlu"] == st0["steps"] + st0["rejects"] + st0["newton_fail"]          # the checker: a matrix per attempt
+        assert st1["nlu"] < 0.35 * st1["steps"] and st1["newton_iters"] < 2.0 * (st1["steps"] + st1["rejects"])   # (SciPy's test: >= 2 per attempt)
+        assert 0.8 * st0["steps"] < st1["steps"] < 1.25 * st0["steps"]
+
+
 def test_my_model_outputs(M, setup):
     cond, guess = setup
     flows, states, stats = M.my_model(M.BASEPARAMS, cond, guess)

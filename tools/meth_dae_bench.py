@@ -19,5 +19,5 @@ for n_part in [int(a) for a in sys.argv[1:]] or [64, 512]:
     dt = time.perf_counter() - t0
     n = len(p0)
     print(f"{n_part} particles x 30 = {n} solves: kernel {info['kernel_ms']:.1f} ms ({n/info['kernel_ms']*1e3:.0f} solves/s), wall {dt:.2f} s, "
-          f"failed {int((status!=0).sum())}, steps/solve {info['steps']/n:.0f}, newton its/solve {info['newton_iters']/n:.0f}, "
+          f"failed {int((status!=0).sum())}, steps/solve {info['steps']/n:.0f}, newton its/solve {info['newton_iters']/n:.0f}, factorisations/solve {info.get('factorisations', 0)/n:.0f}, "
           f"rejects/solve {info['rejects']/n:.1f}, newton fails/solve {info['newton_fail']/n:.2f}", flush=True)
