@@ -36,7 +36,8 @@ extern "C" {
 #endif
 
 #define SMC_ABI_VERSION 3    /* 2: smc_meth_sweep_check writes FIVE words (round 3 added the cancelled count); smc_mh_sweeps_device_rng
-                              * 3: smc_work_totals; smc_mh_sweeps_device_rng takes every model (round 5) */
+                              * 3: smc_work_totals; smc_mh_sweeps_device_rng takes the methanation model too and returns the sweep counters;
+                              *    smc_meth_dae_host's stats have five words (round 5) */
 #define SMC_MAX_DIM 8        /* parameters per particle (3 for Michaelis-Menten, 5 for methanation) */
 #define SMC_MAX_ESS_CAND 16  /* tempering candidates evaluated by one smc_ess_partials call */
 #define SMC_MAX_RANKS 64
@@ -346,11 +347,19 @@ int smc_mh_iteration_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio,
  * if the loop ended by its break (or a failure) - otherwise the caller may enqueue the next batch with mhstep_ratio =
  * ratio_next; per iteration i < n_done (arrays of n_iter entries, each optional): accepted_now/ever and n_failed (all ranks),
  * rk_attempts_local (this rank), ratio_used (the mhstep_ratio it drew with), cov_m (n_iter x d x d, row-major).
- * Michaelis-Menten model only (the other models' sweeps have host-side bookkeeping per sweep). */
+ * sweep_counters (optional, n_iter x SMC_SWEEP_COUNTER_WORDS): this rank's device counters as iteration i left them, in the
+ * order n_failed, rk_attempts (methanation: BDF steps), accepted_now, accepted_ever, newton_iters, factorisations, failed_solves,
+ * expected_solves, completed_solves, unsolved_items, wave_split, cancelled_solves, long_items, solved_items - what
+ * smc_meth_sweep_counters / smc_meth_sweep_check return after a single sweep (after the batch they describe its last sweep).
+ * Michaelis-Menten (carried moments: one all-reduce per iteration) and methanation (np.cov's two passes per iteration: two
+ * all-reduces, the second one carrying the counts); every kernel of an iteration tests the stop flag first, the experiment
+ * order of the methanation sweeps is formed on the device.  A user model takes smc_mh_iteration_device_rng. */
+#define SMC_SWEEP_COUNTER_WORDS 14
 int smc_mh_sweeps_device_rng(smc_ctx *ctx, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed,
                              uint64_t stream0, int n_iter, double thr_stop, double thr_halve, int64_t global_offset,
                              int *n_done, int *stopped, double *ratio_next, int64_t *accepted_now, int64_t *accepted_ever,
-                             int64_t *n_failed, int64_t *rk_attempts_local, double *ratio_used, double *cov_m);
+                             int64_t *n_failed, int64_t *rk_attempts_local, double *ratio_used, double *cov_m,
+                             int64_t *sweep_counters);
 /* The first half of that iteration on its own (no model needed): cov_m = np.cov(p_filt.T, bias=True) * w_cov over all ranks
  * (:212-215) and the factor sqrt(s)[:,None]*v of its SVD, both d x d row-major; either output may be NULL. */
 int smc_proposal_factor_device(smc_ctx *ctx, const double *w_cov, double *cov_m, double *transform);

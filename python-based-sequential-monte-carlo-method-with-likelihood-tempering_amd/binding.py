@@ -21,6 +21,9 @@ PRIOR_MODES = {"mask": 0, "ratio_mask": 1, "ratio": 2}
 RESAMPLING = {"residual_systematic": 0, "systematic": 1, "multinomial": 2}
 SMC_MAX_ESS_CAND = 16
 SMC_ABI_VERSION = 3
+SMC_SWEEP_COUNTER_WORDS = 14
+SWEEP_COUNTER_NAMES = ("n_failed", "rk_attempts", "accepted_now", "accepted_ever", "newton_iters", "factorisations", "failed_solves",
+                       "expected_solves", "completed_solves", "unsolved_items", "wave_split", "cancelled_solves", "long_items", "solved_items")
 SMC_MH_BATCH_MAX = 32
 SMC_T_LOGLIK, SMC_T_MH, SMC_T_ESS, SMC_T_RESAMPLE, SMC_T_MOMENTS, SMC_T_MAX, SMC_T_SOLVE = range(7)
 TIMING_NAMES = {SMC_T_LOGLIK: "loglik", SMC_T_MH: "mh", SMC_T_ESS: "ess", SMC_T_RESAMPLE: "resample",
@@ -87,7 +90,7 @@ SIGNATURES = {
     "smc_pinned_free": (cint, [ctypes.c_void_p]),
     "smc_mh_iteration_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, i64, c_i64p, c_i64p, c_i64p, c_i64p, c_dp]),
     "smc_mh_sweeps_device_rng": (cint, [c_ctx, f64, f64, c_dp, u64, u64, cint, f64, f64, i64, c_ip, c_ip, c_dp, c_i64p, c_i64p,
-                                        c_i64p, c_i64p, c_dp, c_dp]),
+                                        c_i64p, c_i64p, c_dp, c_dp, c_i64p]),
     "smc_mh_iteration_last_transform": (cint, [c_ctx, c_dp]),
     "smc_proposal_factor_device": (cint, [c_ctx, c_dp, c_dp, c_dp]),
     "smc_resample_phase1": (cint, [c_ctx, f64, f64, f64, c_dp, c_i64p]),

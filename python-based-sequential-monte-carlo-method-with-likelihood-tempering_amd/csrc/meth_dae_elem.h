@@ -173,7 +173,7 @@ __device__ __forceinline__ double ipow_small(double x, int n) {   // x^n, 1 <= n
     return r;
 }
 
-// ---- control policy of the integrator (round 5; CPU statement and study: oracle/meth_dae_oracle.c dae_policy,
+// ---- control policy of the integrator (round 5; its CPU statement and the study behind it: the test checker's dae_policy,
 // tools/k8_policy_study.py) ----------------------------------------------------------------------------------------------
 // SMC_K8_POLICY 1 (default): IDA's policy for the iteration matrix and the Newton iteration, restated inside the
 // quasi-constant-step BDF (the reference integrates with IDA: methanation_set_likelihood.py:167-198; SUNDIALS IDA,
@@ -793,7 +793,7 @@ __device__ __forceinline__ void dae_elem_integrate(double *lds, int lane, const 
         // repeating this attempt - when Newton failed on a kept matrix.
         // (Rounds 2-4 tried the pieces of IDA's policy one at a time inside SciPy's control and dropped each: keeping the matrix
         // while c drifts cut the factorisations but raised SciPy-test Newton iterations 720 -> 913; the carried rate alone cut
-        // the iterations 720 -> 435.  Together, with IDA's own convergence constant, they pay: oracle study, then the GPU A/B
+        // the iterations 720 -> 435.  Together, with IDA's own convergence constant, they pay: CPU study, then the GPU A/B
         // in profiles/r05_ab_k8_policy.log.)
         const bool fresh = !lu_valid || force_rebuild || matrix_is_stale(c, c_lu);
 #if SMC_K8_POLICY

@@ -417,8 +417,8 @@ int smc_set_model_methanation(smc_ctx *c, const double *cond, const double *gues
     HIPC(c, hipMalloc(&c->d_mwork, (size_t)c->n_local * n_data * sizeof(int64_t)));
     (void)hipFree(c->d_mstat); (void)hipFree(c->d_morder);
     c->d_mstat = nullptr; c->d_morder = nullptr;
-    c->mstat_pending = c->morder_valid = false;
     HIPC(c, hipMalloc(&c->d_mstat, 2 * (size_t)n_data * sizeof(double)));
+    HIPC(c, hipMemsetAsync(c->d_mstat, 0, 2 * (size_t)n_data * sizeof(double), c->stream));   // no statistics yet: index order
     HIPC(c, hipMalloc(&c->d_morder, (size_t)n_data * sizeof(int)));
     HIPC(c, hipMemcpyAsync(c->d_mcond, cond, (size_t)n_data * 10 * 8, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipMemcpyAsync(c->d_mguess, guess, (size_t)n_data * 357 * 8, hipMemcpyHostToDevice, c->stream));
@@ -1475,17 +1475,23 @@ int smc_mh_iteration_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, c
 int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, const double *w_cov, uint64_t seed, uint64_t stream0,
                              int n_iter, double thr_stop, double thr_halve, int64_t global_offset, int *n_done, int *stopped,
                              double *ratio_next, int64_t *accepted_now, int64_t *accepted_ever, int64_t *n_failed,
-                             int64_t *rk_attempts_local, double *ratio_used, double *cov_m) {
+                             int64_t *rk_attempts_local, double *ratio_used, double *cov_m, int64_t *sweep_counters) {
     if (!c) return fail(nullptr, "NULL context");
     if (!c->have_model || !c->have_prior) return fail(c, "model and prior must be set before an MH step");
-    if (c->model_kind != 1) return fail(c, "smc_mh_sweeps_device_rng: Michaelis-Menten model only (the other models take smc_mh_iteration_device_rng)");
+    if (c->model_kind != 1 && c->model_kind != 2)
+        return fail(c, "smc_mh_sweeps_device_rng: Michaelis-Menten and methanation models (a user model takes smc_mh_iteration_device_rng)");
     if (!w_cov) return fail(c, "smc_mh_sweeps_device_rng: w_cov is NULL");
     if (n_iter < 1 || n_iter > kMHBatchMax) return fail(c, "smc_mh_sweeps_device_rng: n_iter must be 1 .. 32");
     if (c->world > 1 && !can_reduce(c)) return fail(c, "world > 1 but smc_comm_init has not been called (the batch needs RCCL)");
     HIPC(c, hipSetDevice(c->device));
-    const int d = c->dim, nv = d + d * (d + 1) / 2;
+    const bool mm = c->model_kind == 1;
+    const int d = c->dim, npair = d * (d + 1) / 2;
+    const int nv = mm ? d + npair : 0;         // carried moments in front of the counts (Michaelis-Menten accept kernel only)
     const bool one_rank = !can_reduce(c);      // a one-rank RCCL communicator (tests) takes the several-ranks path as well
     double *S = c->d_fused;
+    // where an iteration's [moments | accepted_now, accepted_ever, n_failed] vector lives: Michaelis-Menten S + kV (carried
+    // moments); the other models right behind the centred sums of the two-pass covariance, so that ONE all-reduce takes both
+    double *vec = mm ? S + kV : S + kCent + npair;
     MHControlArgs a{};
     a.ctl = c->d_mhctl;
     a.log = c->d_mhlog;
@@ -1493,7 +1499,7 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
     a.thr_stop = thr_stop;
     a.thr_halve = thr_halve;
     a.nv = nv;
-    a.vec = S + kV;
+    a.vec = vec;
     a.counters = c->d_counters;
     a.n_global = (double)c->n_global;
     a.shift_io = S + kShift;
@@ -1509,19 +1515,24 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
         c->moments_valid = false;
         return 1;
     };
+    // np.cov's two-pass route over the FILT set as it is now (:212): column sums -> [all-reduce] -> sums centred about the global
+    // mean [+ `extra` words behind them] -> [all-reduce]
+    auto two_pass = [&](int extra) {
+        launch_moment_sums(c, S + kSums);
+        if (dev_allreduce(c, S + kSums, (size_t)d, ncclDouble, ncclSum)) return 1;
+        launch_moment_centered_dev(c, S + kSums, S + kCent);
+        return dev_allreduce(c, S + kCent, (size_t)(npair + extra), ncclDouble, ncclSum);
+    };
     ScopedTimer tm_mh(c, SMC_T_MH);
-    {   // the first iteration's factor: carried moments, or np.cov's two-pass route when the FILT set changed since
+    {   // the first iteration's factor: carried moments, or the two-pass route when the FILT set changed since
         ScopedTimer tm(c, SMC_T_MOMENTS);
         a.mode = kCtlInit | kCtlTransform;
         a.iteration = 0;
-        if (c->moments_valid) {
+        if (mm && c->moments_valid) {
             a.mom = S + kV;
             a.sums = nullptr;
         } else {
-            launch_moment_sums(c, S + kSums);
-            if (dev_allreduce(c, S + kSums, (size_t)d, ncclDouble, ncclSum)) return bail();
-            launch_moment_centered_dev(c, S + kSums, S + kCent);
-            if (dev_allreduce(c, S + kCent, (size_t)(d * (d + 1) / 2), ncclDouble, ncclSum)) return bail();
+            if (two_pass(0)) return bail();
             a.mom = S + kCent;
             a.sums = S + kSums;
         }
@@ -1540,48 +1551,86 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
         mh.global_offset = global_offset;
         mh.transform_dev = S + kXf;
         mh.zero_counters = c->d_counters;
-        mh.zero_queue = c->d_queue;
-        mh.moment_shift = S + kShift;
-        mh.moment_rows = c->d_partials;
         mh.ctl = c->d_mhctl;
-        launch_mm_mh(c, c->n_local, mh);
+        if (mm) {
+            mh.zero_queue = c->d_queue;
+            mh.moment_shift = S + kShift;
+            mh.moment_rows = c->d_partials;
+            launch_mm_mh(c, c->n_local, mh);
+        } else {
+            launch_meth_mh(c, c->n_local, mh);
+        }
         if (hipGetLastError() != hipSuccess) { fail(c, "smc_mh_sweeps_device_rng: a kernel launch of the batch failed"); return bail(); }
         if (c->launch_failed) { c->launch_failed = false; return bail(); }
-        if (!one_rank) {
-            launch_moments_reduce(c, c->moment_rows_n, nv, S + kV, c->d_mhctl);
-            if (dev_allreduce(c, S + kV, (size_t)nv + 3, ncclDouble, ncclSum)) return bail();
-        }
+        const bool transform_next = i + 1 < n_iter;
         ScopedTimer tm(c, SMC_T_MOMENTS);
-        a.mode = kCtlDecide | (i + 1 < n_iter ? kCtlTransform : 0);
+        if (mm) {
+            if (!one_rank) {
+                launch_moments_reduce(c, c->moment_rows_n, nv, vec, c->d_mhctl);
+                if (dev_allreduce(c, vec, (size_t)nv + 3, ncclDouble, ncclSum)) return bail();
+            }
+            a.rows = one_rank ? c->d_partials : nullptr;
+            a.n_rows = c->moment_rows_n;
+            a.counts_local = 0;
+            a.mom = S + kV;
+            a.sums = nullptr;
+        } else {
+            // no carried moments: the next iteration's covariance is the two-pass one of the FILT set this iteration's accept
+            // kernel has just left - its second all-reduce also carries the counts.  (Computed even when the loop then turns
+            // out to have ended: the collectives of all ranks stay matched; the values are not used.)
+            a.rows = nullptr;
+            a.n_rows = 0;
+            a.counts_local = one_rank ? 1 : 0;
+            if (!one_rank) launch_moments_reduce(c, 0, 0, vec, c->d_mhctl);
+            if (transform_next) {
+                if (two_pass(one_rank ? 0 : 3)) return bail();
+            } else if (!one_rank && dev_allreduce(c, vec, 3, ncclDouble, ncclSum)) {
+                return bail();
+            }
+            a.mom = S + kCent;
+            a.sums = S + kSums;
+        }
+        a.mode = kCtlDecide | (transform_next ? kCtlTransform : 0);
         a.iteration = i + 1;
-        a.rows = one_rank ? c->d_partials : nullptr;
-        a.n_rows = c->moment_rows_n;
-        a.mom = S + kV;
-        a.sums = nullptr;
         launch_mh_control(c, a, w_cov);
     }
-    HIPC(c, hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { fail(c, "smc_mh_sweeps_device_rng: a kernel launch of the batch failed"); return bail(); }
     HIPC(c, hipMemcpyAsync(c->h_mhlog, c->d_mhlog, (size_t)(n_iter + 1) * sizeof(MHLogEntry), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipMemcpyAsync(c->h_mhctl, c->d_mhctl, sizeof(MHControl), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipMemcpyAsync(c->h_fused, S, (size_t)kFusedWords * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));          // the one synchronisation of the batch
     const int done = c->h_mhctl->n_done;
     if (done < 1 || done > n_iter) return fail(c, "smc_mh_sweeps_device_rng: the device reports an impossible iteration count");
-    c->moments_valid = true;           // S + kV: moments of the particles the last iteration that ran selected
-    c->stiff_parity = parity0 ^ (done & 1);     // the lists of the iterations after the break were never built: their counters
-                                                // are as the last iteration that ran left them (cleared for its successor)
-    c->pending_sweep_items = 0;
-    c->last_sweep_items = c->n_local * c->mm.n_ex;
-    c->last_sweep_long_items = (int64_t)c->h_mhlog[done - 1].long_items;
+    c->moments_valid = mm;             // S + kV: moments of the particles the last iteration that ran selected
+    *c->h_counters = c->h_mhlog[done - 1].snap;        // what smc_meth_sweep_counters / smc_meth_sweep_check report: the last sweep that ran
+    if (mm) {
+        c->stiff_parity = parity0 ^ (done & 1);     // the lists of the iterations after the break were never built: their counters
+                                                    // are as the last iteration that ran left them (cleared for its successor)
+        c->pending_sweep_items = 0;
+        c->last_sweep_items = c->n_local * c->mm.n_ex;
+        c->last_sweep_long_items = (int64_t)c->h_mhlog[done - 1].long_items;
+        c->w_solve_launches += done;
+        c->w_noop_launches += n_iter - done;
+    }
     if (n_done) *n_done = done;
     if (stopped) *stopped = c->h_mhctl->stop;
     if (ratio_next) *ratio_next = c->h_mhctl->ratio;
-    c->w_solve_launches += done;
-    c->w_noop_launches += n_iter - done;
+    static_assert(sizeof(SweepCounters) == SMC_SWEEP_COUNTER_WORDS * sizeof(unsigned long long), "include/smc_hip.h: SMC_SWEEP_COUNTER_WORDS");
     for (int i = 0; i < done; ++i) {
         const MHLogEntry &e = c->h_mhlog[i];
-        c->w_solved_items += (int64_t)e.solved_items;
-        c->w_rk_attempts += (int64_t)e.rk_attempts;
+        if (mm) {
+            c->w_solved_items += (int64_t)e.solved_items;
+            c->w_rk_attempts += (int64_t)e.rk_attempts;
+        } else {   // every (particle, experiment) item the sweep asked for must have been solved or cancelled exactly once
+            const SweepCounters &k = e.snap;
+            if (k.completed_solves + k.cancelled_solves != k.expected_solves || k.unsolved_items != 0 || k.wave_split != 0) {
+                char buf[320];
+                snprintf(buf, sizeof buf, "methanation sweep %d of the batch incomplete: %llu of %llu DAE solves finished (+ %llu cancelled "
+                         "by the exact early rejection), %llu live items unsolved, %llu waves split at a dequeue", i, k.completed_solves,
+                         k.expected_solves, k.cancelled_solves, k.unsolved_items, k.wave_split);
+                return fail(c, buf);
+            }
+        }
         if (accepted_now) accepted_now[i] = (int64_t)e.accepted_now;
         if (accepted_ever) accepted_ever[i] = (int64_t)e.accepted_ever;
         if (n_failed) n_failed[i] = (int64_t)e.n_failed;
@@ -1589,6 +1638,7 @@ int smc_mh_sweeps_device_rng(smc_ctx *c, double gamma, double mhstep_ratio, cons
         if (ratio_used) ratio_used[i] = e.ratio;
         if (cov_m)
             for (int q = 0; q < d * d; ++q) cov_m[(size_t)i * d * d + q] = e.cov[q];
+        if (sweep_counters) memcpy(sweep_counters + (size_t)i * SMC_SWEEP_COUNTER_WORDS, &e.snap, sizeof(SweepCounters));
     }
     return 0;
 }

@@ -177,7 +177,6 @@ struct smc_ctx {
     int64_t *d_mwork = nullptr;      // work list of an MH sweep: the live proposals, compacted
     double *d_mstat = nullptr;       // 2 x n_data: per experiment, sum of log1p(misfit) and count over the last sweep's solves
     int *d_morder = nullptr;         // n_data: the order in which the next sweep solves the experiments (most misfit first)
-    bool mstat_pending = false, morder_valid = false;
     bool have_model = false, have_prior = false;
     smc::MMModel mm{};
     double *d_t = nullptr, *d_P = nullptr, *d_S0 = nullptr;

@@ -69,7 +69,7 @@ class SMCSettings:
     defer_resample: bool = True       # enqueue the resampling without a host synchronisation (one rank; HipEngine.resample_enqueue)
     pinned_results: bool = True       # final particles / likelihoods arrive in page-locked host arrays (HipEngine.download_*(pinned=True))
     mh_batch: object = "auto"         # Metropolis iterations enqueued per host synchronisation, their loop control (main:243-249) on the
-                                      # device (HipEngine.mh_sweeps_device_rng; device RNG, Michaelis-Menten): "auto" = as many as the
+                                      # device (HipEngine.mh_sweeps_device_rng; device RNG; not for user models): "auto" = as many as the
                                       # previous tempering step needed, an int = that many, 0 = one call and one decision per iteration
     priors: dict = field(default_factory=lambda: {
         "Vmax": {"dist": "uniform", "low": 0, "high": 10},
@@ -357,14 +357,19 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
 
     meth = getattr(engine, "model", ("",))[0] == "methanation"
 
-    def account(info):
+    def account(info, counters=None):
         stats["rk_attempts"] += info["rk_attempts"]
         stats["n_failed"] += info["n_failed"]
         if meth:                                   # K8 work counters of the sweep just done
-            for k, v in engine.meth_sweep_counters().items():
+            if counters is None:                   # one sweep per call: the engine's last-sweep counters
+                k8, chk = engine.meth_sweep_counters(), engine.meth_sweep_check()
+            else:                                  # an iteration of a batch: its own snapshot from the batch log
+                k8 = {"bdf_steps": counters["rk_attempts"], "newton_iters": counters["newton_iters"],
+                      "factorisations": counters["factorisations"], "failed_solves": counters["failed_solves"]}
+                chk = counters
+            for k, v in k8.items():
                 stats[k] = stats.get(k, 0) + v
-            chk = engine.meth_sweep_check()        # solves done / skipped by the exact early rejection
-            stats["dae_solves"] = stats.get("dae_solves", 0) + chk["completed_solves"]
+            stats["dae_solves"] = stats.get("dae_solves", 0) + chk["completed_solves"]      # solves done / skipped by the exact early rejection
             stats["dae_solves_cancelled"] = stats.get("dae_solves_cancelled", 0) + chk.get("cancelled_solves", 0)
 
     gamma_old, gamma_new = 0.0, 1.0
@@ -444,7 +449,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
         mh_log = []
         fused = rng == "device" and _on_device(comm)
         batched = (fused and s.mh_batch not in (0, None) and getattr(engine, "mh_sweeps_device_rng", None) is not None
-                   and getattr(engine, "model", ("",))[0] == "mm")
+                   and getattr(engine, "model", ("",))[0] in ("mm", "methanation"))
         if batched:
             # The same loop with its control on the device: the iterations are enqueued back to back, the engine's control
             # kernel takes the decisions of :243-249 between them, and the host synchronises once per batch (as a rule once per
@@ -461,7 +466,7 @@ def run_smc(engine, s: SMCSettings | None = None, comm=None, rng: str = "numpy",
                 stats["mh_syncs"] += 1
                 stats["mh_noop_sweeps"] += k - out["n_done"]
                 for it in out["iterations"]:
-                    account({"rk_attempts": it["rk_attempts"], "n_failed": 0})
+                    account({"rk_attempts": it["rk_attempts"], "n_failed": 0}, it.get("counters"))
                     stats["rk_attempts_mh"] += it["rk_attempts"]
                     stats["mutation_sweeps"] += 1
                     stats["particle_mutation_steps"] += n

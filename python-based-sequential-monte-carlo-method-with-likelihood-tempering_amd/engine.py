@@ -408,13 +408,16 @@ class HipEngine:
         nd, st, rn = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_double(0)
         an, ae, nf, at = (np.zeros(k, dtype=np.int64) for _ in range(4))
         ru, cov = np.zeros(k), np.zeros((k, self.dim, self.dim))
+        sc = np.zeros((k, B.SMC_SWEEP_COUNTER_WORDS), dtype=np.int64)
         self._ck(self.L.smc_mh_sweeps_device_rng(self.ctx, float(gamma), float(mhstep_ratio), _dp(w_cov), int(seed), int(stream0), k,
                                                  float(thr_stop), float(thr_halve), int(global_offset), ctypes.byref(nd),
                                                  ctypes.byref(st), ctypes.byref(rn), an.ctypes.data_as(B.c_i64p),
                                                  ae.ctypes.data_as(B.c_i64p), nf.ctypes.data_as(B.c_i64p),
-                                                 at.ctypes.data_as(B.c_i64p), _dp(ru), _dp(cov)), "smc_mh_sweeps_device_rng")
+                                                 at.ctypes.data_as(B.c_i64p), _dp(ru), _dp(cov), sc.ctypes.data_as(B.c_i64p)),
+                 "smc_mh_sweeps_device_rng")
         its = [{"accepted_now": int(an[i]), "accepted_ever": int(ae[i]), "n_failed": int(nf[i]), "rk_attempts": int(at[i]),
-                "mhstep_ratio": float(ru[i]), "cov_m": cov[i].copy()} for i in range(nd.value)]
+                "mhstep_ratio": float(ru[i]), "cov_m": cov[i].copy(),
+                "counters": {nm: int(sc[i, q]) for q, nm in enumerate(B.SWEEP_COUNTER_NAMES)}} for i in range(nd.value)]
         return {"n_done": nd.value, "stopped": bool(st.value), "ratio_next": rn.value, "iterations": its}
 
     def proposal_factor_device(self, w_cov):

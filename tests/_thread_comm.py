@@ -48,3 +48,10 @@ class ThreadComm:
 
     def barrier(self):
         self.w.barrier.wait()
+
+
+class PeerComm(ThreadComm):
+    """The same threads, but with the collectives of the hot path INSIDE the engines (HipEngine.debug_peer_collectives): the
+    driver then takes the *_global / fused / batched entry points - the world > 1 branches a run over RCCL takes - and only
+    the few host-side reductions of run_smc (failure counts, barriers) go through the Python slots."""
+    on_device = True

@@ -541,7 +541,7 @@ def test_sharded_methanation_run_equals_single_rank(pkg, M, cond_guess, world):
     generic_accept_kernel / meth_certainly_rejected (global_offset = rank * n_local), and the per-rank misfit order of the
     experiments (every rank orders by its own block's statistics - any order must give the same results).
     Device-RNG mode is keyed by the global index, so the sharded run must reproduce the one-rank run: tempering schedule,
-    Metropolis lengths, accept counts and offspring counts exactly; particles to 1e-9, likelihoods to 1e-6, evidence to 1e-7 (the
+    Metropolis lengths, accept counts and offspring counts exactly; particles to 1e-9, likelihoods to 1e-5, evidence to 1e-6 (the
     cross-rank moment sums round differently from one block's tree, so proposals may differ in the last bits)."""
     cond, guess = cond_guess
     np.random.seed(20250205)
@@ -557,15 +557,19 @@ def test_sharded_methanation_run_equals_single_rank(pkg, M, cond_guess, world):
         assert [r["last_j"] for r in o["records"]] == [r["last_j"] for r in ref["records"]]
         assert [r["n_accept"] for r in o["records"]] == [r["n_accept"] for r in ref["records"]]
         assert [r["n_offspring"] for r in o["records"]] == [r["n_offspring"] for r in ref["records"]]
-        assert abs(o["logZ"] - ref["logZ"]) <= 1e-7 * abs(ref["logZ"])          # a sum over likelihoods that agree to ~1e-7 (below)
+        assert abs(o["logZ"] - ref["logZ"]) <= 1e-6 * abs(ref["logZ"])          # a sum over likelihoods that agree to ~1e-6 (below)
     p = np.concatenate([o["p_pred"] for o in outs])
     lk = np.concatenate([o["lk"] for o in outs])
     assert p.shape == ref["p_pred"].shape
     assert (np.abs(p - ref["p_pred"]) / np.maximum(1.0, np.abs(ref["p_pred"]))).max() < 1e-9
-    # likelihoods: 1e-6 relative.  A proposal that differs in its last bit can change one accept / reject decision of the BDF step
-    # controller, which moves the outlet flows by a fraction of the integrator's tolerance (rtol = atol = 1e-6): observed 1.1e-7
-    # relative on logL ~ -320, and none of these differences flipped a Metropolis decision (the counts above are exact)
-    assert (np.abs(lk - ref["lk"]) / np.maximum(1.0, np.abs(ref["lk"]))).max() < 1e-6
+    # likelihoods: 1e-5 relative = the integrator's own tolerance seen through the likelihood.  A proposal that differs in its last
+    # bit can change one accept / reject decision of the BDF step controller or one Newton iteration count, which moves the outlet
+    # flows by a fraction of the integrator's tolerance (rtol = atol = 1e-6 on flows of O(100) with sigma ~ 5: up to ~3e-3 on logL
+    # ~ -320).  Observed: 1.1e-7 relative with round 4's control policy (Newton converged to 1e-3 tolerance units), 1.0e-6 with
+    # round 5's (IDA's 0.33); none of these differences flipped a Metropolis decision (the counts above are exact).  K8's results
+    # are defined up to the integrator's tolerance, and the number of ranks enters through the rounding of the moment sums only
+    # (DESIGN.md 5).
+    assert (np.abs(lk - ref["lk"]) / np.maximum(1.0, np.abs(ref["lk"]))).max() < 1e-5
     # every rank solved (or cancelled) exactly its own block's items in every sweep: the library's own check passed in each
     # sweep (smc_meth_sweep_check), and the blocks' solve counts add up to the one-rank run's
     tot = sum(o["stats"]["dae_solves"] + o["stats"]["dae_solves_cancelled"] for o in outs)
