@@ -11,18 +11,18 @@ set -e
 log "bench 20/5 (clean)"
 timeout -k 10 300 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_mm.json 2> $O/bench_mm.err
 log "kernel stats"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_mm_under_rocprof.json 2> $O/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_mm_under_rocprof.json 2> $O/stats.err
 log "pmc fetch"
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> $O/pmc_fetch.err
 log "pmc write"
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2> $O/pmc_write.err
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU" "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_WAVES SQ_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS"; do
   i=$((i+1))
   log "sq pass $i (steady state)"
   timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sq$i -- python3 $R/tools/steady_state.py 1000000 1 > $O/sq$i.log 2>&1
   log "sq pass $i (whole run)"
-  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sqrun$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/sqrun$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/sqrun$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $O/sqrun$i.log 2>&1
 done
 log "methanation N = 1024 under rocprof"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/meth_stats -o run -- python3 $R/bench.py --workload methanation --particles-per-gpu 1024 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_methanation_n1024_under_rocprof.json 2> $O/meth_stats.err
