@@ -203,9 +203,19 @@ MM_KERNEL_SOURCES = ("csrc/mm_kernels.hip", "csrc/mm_rk45.h", "csrc/rk45_math.h"
 
 # ... and of K8, the methanation DAE kernel (meth_smc.hip and everything it includes).  The launches use the two-wave kernel
 # (meth_dae_split.h) unless SMC_K8_SPLIT=0 asks for the one-wave kernel of rounds 1-4 (bit-identical results, A/B runs)
-def k8_kernel_name():
-    return "meth_particles_dae_kernel" if os.environ.get("SMC_K8_SPLIT", "1") in ("0", "") else "meth_particles_dae_split_kernel"
+def k8_split_enabled():
+    """SMC_K8_SPLIT as the library reads it (csrc/meth_dae_split.h: meth_split_enabled - C's atoi: leading white space, an optional
+    sign, then digits; anything that does not start like a number is 0 = off; unset = on)."""
+    import re
+    e = os.environ.get("SMC_K8_SPLIT")
+    if e is None:
+        return True
+    m = re.match(r"\s*([+-]?\d+)", e)
+    return bool(m) and int(m.group(1)) != 0
 
+
+def k8_kernel_name():
+    return "meth_particles_dae_split_kernel" if k8_split_enabled() else "meth_particles_dae_kernel"
 
 
 K8_KERNEL_SOURCES = ("csrc/meth_smc.hip", "csrc/meth_dae_split.h", "csrc/meth_dae_elem.h", "csrc/meth_dae_wave.h", "csrc/meth_dae.h", "csrc/meth_model.h",

@@ -16,9 +16,15 @@
 //     L_i G_{i-1}, upwards U_i H_{i+1}, and both are  c1[mr] g[mr][mc] + c2[mr] g[mr < 6 ? 6 : 5][mc]  with the right slots;
 //   * the waves meet at node 25: H_26 and X_25 cross through one 64-word LDS row, z_24 / w_26 through 2 x 7 words, and both
 //     waves solve the middle node redundantly (no extra barrier before the solution runs outwards);
-//   * synchronisation is a command protocol with a FIXED number of s_barriers per command (FACTOR: dispatch, F1, F2;  SOLVE:
-//     dispatch, A, C;  QUIT: dispatch), so the two waves cannot disagree on the next barrier: wave 1 takes no decision of its
-//     own.  Every word that crosses is written before one barrier and read after it, and not rewritten before the next.
+//   * synchronisation is a command protocol with a FIXED number of s_barriers per command - FACTOR: dispatch, one per staging
+//     pass of the Jacobian blocks (7: one block row of all nodes per pass, two staging rows in turn), F1, F2 = 10;  SOLVE:
+//     dispatch, A, C = 3;  QUIT: dispatch = 1 - executed by BOTH waves, so the two cannot disagree on the next barrier: wave 1
+//     takes no decision of its own.  Every word that crosses is written before one barrier and read after it, and not rewritten
+//     before the next.  (tests/test_k8_uniform_control.py: no barrier sits under a divergent branch.)
+//   * a factorisation fails (-> Newton failure, halved step) when an inverse block has an entry that is not below 1e300 in
+//     magnitude - ONE test per inverse since round 4; rounds 1-3 tested every pivot against a relative threshold
+//     (gj_pivot_ok), which the two chains' shared basic block does not allow.  Near-singular matrices that passed neither test
+//     fail either way; between the two, the Newton iteration's own divergence test catches a bad factorisation.
 // (A first version ran everything that is parallel over nodes in BOTH waves on half the nodes each: correct, but 1.45 x the
 // vector instructions of v3 and 6 % slower - with two waves per SIMD the instruction count is what matters.  Here wave 1 is
 // idle while wave 0 evaluates residuals and norms, and the SIMD's other wave has the issue slots.)

@@ -29,15 +29,23 @@ class _PinnedPool:
     """Page-locked host buffers for downloaded results (include/smc_hip.h: smc_pinned_alloc).  A buffer belongs to the NumPy array
     that views it and returns to the pool when that array (and every view of it) is garbage-collected; the memory is
     process-wide, so such an array stays valid after its engine is closed.  Buffers are reused by size: a run's final 24 + 8 MB
-    download costs one DMA transfer each instead of the runtime's staged copy into pageable memory."""
+    download costs one DMA transfer each instead of the runtime's staged copy into pageable memory.
+    Thread-safe (several engines may run in threads of one process); at most `cap_bytes` of returned buffers are kept - what
+    exceeds the cap is unpinned and freed at once (smc_pinned_free), and release() / interpreter exit free the rest."""
 
-    def __init__(self):
+    def __init__(self, cap_bytes=1 << 30):
+        import threading
         self.free = {}          # nbytes -> [ptr, ...]
+        self.pooled = 0         # bytes held in `free`
+        self.cap_bytes = int(cap_bytes)
+        self.lock = threading.Lock()
 
     def take(self, nbytes):
-        lst = self.free.get(nbytes)
-        if lst:
-            return lst.pop()
+        with self.lock:
+            lst = self.free.get(nbytes)
+            if lst:
+                self.pooled -= nbytes
+                return lst.pop()
         p = ctypes.c_void_p(0)
         st = lib().smc_pinned_alloc(ctypes.c_size_t(nbytes), ctypes.byref(p))
         if st != 0:
@@ -46,10 +54,34 @@ class _PinnedPool:
         return p.value
 
     def give(self, ptr, nbytes):
-        self.free.setdefault(nbytes, []).append(ptr)
+        with self.lock:
+            if self.pooled + nbytes <= self.cap_bytes:
+                self.free.setdefault(nbytes, []).append(ptr)
+                self.pooled += nbytes
+                return
+        lib().smc_pinned_free(ctypes.c_void_p(ptr))
+
+    def release(self):
+        """Unpin and free every buffer the pool holds (buffers still owned by live arrays are not touched)."""
+        with self.lock:
+            ptrs = [p for lst in self.free.values() for p in lst]
+            self.free.clear()
+            self.pooled = 0
+        for p in ptrs:
+            lib().smc_pinned_free(ctypes.c_void_p(p))
 
 
 _PINNED = _PinnedPool()
+
+
+def release_pinned_pool():
+    """Free the page-locked result buffers that are waiting for reuse (a size sweep would otherwise keep them for the life of the process)."""
+    _PINNED.release()
+
+
+import atexit  # noqa: E402
+
+atexit.register(lambda: _PINNED.release() if B._LIB is not None else None)
 
 
 class _PinnedOwner:
