@@ -370,6 +370,32 @@ struct SolveArgs {              // everything the attempt loops do not touch sta
     const MHControl *ctl;           // batch of iterations under device control: the kernel leaves at once when ctl->stop is set
 };
 
+// A kernel argument as a scalar register of its OWN.  The kernel's arguments arrive in 4-, 8- and 16-dword loads, i.e. as
+// register TUPLES; when the allocator runs out of scalar registers it spills and reloads a tuple as a whole - in round 4's
+// kernel the bulk attempt loop reloaded all 16 dwords of one (16 v_readlane per attempt, vector-ALU slots in an issue-bound loop)
+// to get at rtol and atol, and 4 + 4 more for the two pointers of publish_item (tools/bulk_loop_report.py).  The empty asm makes
+// the value opaque: what the loop uses is a 1- or 2-dword register that can be kept or spilled on its own.
+#ifdef SMC_NO_OWN_SGPR   // A/B builds: round 4's kernel (arguments used straight out of their tuples, no waves-per-SIMD request)
+template <class T> __device__ __forceinline__ T own_sgpr(T v) { return v; }
+#else
+__device__ __forceinline__ double own_sgpr(double v) {
+    double r;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(v));      // (an explicit move: a tied "+s" operand is coalesced back into the tuple)
+    return r;
+}
+template <class T>
+__device__ __forceinline__ T *own_sgpr(T *p) {
+    T *r;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(r) : "s"(p));
+    return r;
+}
+__device__ __forceinline__ int own_sgpr(int v) {
+    int r;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(v));
+    return r;
+}
+#endif
+
 // one experiment's term of logL (Micmem_likelihood.py:70-73), shared by the accept kernel and by the rejection bound so that
 // both evaluate the same floating-point expression
 __device__ __forceinline__ double mm_loglik_term(double c0, double sum_r2, double s2) { return c0 - sum_r2 / (2.0 * s2); }
@@ -378,10 +404,13 @@ __device__ __forceinline__ double mm_loglik_term(double c0, double sum_r2, doubl
 // ONE relaxed agent-scope 8-byte store (write-through, no fence: a release per item tripled the time of a sweep).  The
 // sum itself says whether the item is finished (see kSumCancelled), so no ordering with the info word is needed; the info
 // word is only read by the accept kernel, after this kernel has ended.
-__device__ __forceinline__ void publish_item(const SolveArgs &a, int64_t idx, double sum_r2, int info) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.sum_r2) + idx, (unsigned long long)__double_as_longlong(sum_r2),
+__device__ __forceinline__ void publish_item(double *sums, int *infos, int64_t idx, double sum_r2, int info) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(sums) + idx, (unsigned long long)__double_as_longlong(sum_r2),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.info[idx] = info;
+    infos[idx] = info;
+}
+__device__ __forceinline__ void publish_item(const SolveArgs &a, int64_t idx, double sum_r2, int info) {
+    publish_item(a.sum_r2, a.info, idx, sum_r2, info);
 }
 
 // EXACT early rejection.  The accept test of the sweep (Micmem_SMC_main.py:231-236) is  exp((lk2 - lk1) * gamma) [* p0_2/p0_1]
@@ -455,6 +484,8 @@ struct MMOps {
     double rtol, atol;
     int patience;
     long long n_pos;            // positions of the index-ordered pass
+    double *pub_sums;           // a.sum_r2 / a.info as registers of their own (own_sgpr): what finish() inside the attempt loop uses
+    int *pub_info;
 
     __device__ __forceinline__ int start(long long p, int e, bool from_list, Item &nb) const {
         // masked proposal: lk2 == lk1, no solve (a cost-ordered sweep holds none: the propose kernel has published them)
@@ -556,7 +587,7 @@ struct MMOps {
     }
     __device__ __forceinline__ void finish(Item &it, int st) const {
         const bool ok = (st == 1) && (it.s.i_out == n_t);
-        publish_item(a, it.out_idx, ok ? it.s.sum_r2 : quiet_nan(), it.s.attempts | (ok ? 0 : kInfoFailed));
+        publish_item(pub_sums, pub_info, it.out_idx, ok ? it.s.sum_r2 : quiet_nan(), it.s.attempts | (ok ? 0 : kInfoFailed));
         if (WRITE_PRED && !ok)
             for (int i = it.s.i_out; i < n_t; ++i) it.pred[i] = quiet_nan();
     }
@@ -591,13 +622,8 @@ struct MMOps {
     }
 };
 
-#ifdef SMC_SOLVE_WAVES   // A/B knob: waves per SIMD the register allocation is limited to
-#define SMC_SOLVE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(SMC_SOLVE_WAVES, SMC_SOLVE_WAVES)))
-#else
-#define SMC_SOLVE_WAVES_ATTR
-#endif
 template <bool WRITE_PRED, bool EXACT, bool FAST>
-__global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_kernel(MMModel mm, SolveArgs a) {
+__device__ __forceinline__ void mm_solve_body(const MMModel &mm, const SolveArgs &a) {
     extern __shared__ double2 smem_tp[];
     if (a.ctl && __builtin_amdgcn_readfirstlane(a.ctl->stop)) return;   // the Metropolis loop has ended: nothing to solve (scalar branch)
     const int n_ex = mm.n_ex, n_t = mm.n_t;
@@ -611,11 +637,30 @@ __global__ void __launch_bounds__(kSolveBlock) SMC_SOLVE_WAVES_ATTR mm_solve_ker
     const unsigned n_stiff = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[0]) : 0u;
     unsigned n_solo = a.stiff_list ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.stiff_count[1]) : 0u;
     if (n_solo > a.solo_cap) n_solo = a.solo_cap;   // the overflow went onto the ordinary list (stiff_list_append)
-    MMOps<WRITE_PRED, EXACT, FAST> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, n_t, a.stiff_list, n_stiff,
-                                 a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, mm.rtol, mm.atol, a.patience,
-                                 a.n_ordered ? (long long)__builtin_amdgcn_readfirstlane((int)a.n_ordered[0]) : (long long)a.n};
+    MMOps<WRITE_PRED, EXACT, FAST> ops{mm, a, s_tp, s_S0, (long long)a.n, n_ex, own_sgpr(n_t), a.stiff_list, n_stiff,
+                                 a.stiff_list ? a.stiff_list + (a.stiff_cap - 1) : nullptr, n_solo, own_sgpr(mm.rtol), own_sgpr(mm.atol),
+                                 own_sgpr(a.patience),
+                                 a.n_ordered ? (long long)__builtin_amdgcn_readfirstlane((int)a.n_ordered[0]) : (long long)a.n,
+                                 own_sgpr(a.sum_r2), own_sgpr(a.info)};
     solve_persistent(ops, a.queue, s_pool);
 }
+// The kernel: the primary template serves the parity arithmetic (EXACT: 164 VGPRs, three waves per SIMD); the default-mode
+// instantiations are explicit specialisations that ask for FOUR waves per SIMD (128 VGPRs) - with the kernel arguments of the
+// attempt loop in registers of their own the allocator otherwise lands on 130.
+template <bool WRITE_PRED, bool EXACT, bool FAST>
+__global__ void __launch_bounds__(kSolveBlock) mm_solve_kernel(MMModel mm, SolveArgs a) {
+    mm_solve_body<WRITE_PRED, EXACT, FAST>(mm, a);
+}
+#ifndef SMC_NO_OWN_SGPR
+#define SMC_SOLVE_DEFAULT_MODE(WP, F)                                                                                              \
+    template <>                                                                                                                    \
+    __global__ void __launch_bounds__(kSolveBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) mm_solve_kernel<WP, false, F>(MMModel mm, SolveArgs a) { \
+        mm_solve_body<WP, false, F>(mm, a);                                                                                        \
+    }
+SMC_SOLVE_DEFAULT_MODE(false, false)     // (the WRITE_PRED instantiations - predictions for the drop-in's plots - stay with the primary template)
+SMC_SOLVE_DEFAULT_MODE(false, true)
+#undef SMC_SOLVE_DEFAULT_MODE
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // finish: logL from the per-experiment sums, then store or accept/select

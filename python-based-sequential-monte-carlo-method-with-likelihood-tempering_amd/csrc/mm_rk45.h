@@ -146,6 +146,9 @@ __device__ __forceinline__ bool mm_item_begin(MMItem &it, double Vmax, double Km
         return false;
     }
     it.t_next = t0;
+#ifdef SMC_PROBE_NO_OUTPUTS   // timing probe only (wrong results): no data time is ever due, the dense-output path never runs
+    it.t_next = __longlong_as_double(0x7ff0000000000000LL);
+#endif
     it.min_step = min_step_of(it.t);
     if (it.h_abs < it.min_step) it.h_abs = it.min_step;  // rk.py:122-127 (max_step = inf)
     return true;
