@@ -457,3 +457,291 @@ int dae_bdf_test_ode(const double *y0_3, const double *k3, double tf, double rto
     y3[0] = y[0]; y3[1] = y[NX]; y3[2] = y[2 * NX];
     return rc;
 }
+
+/* =====================================================================================================================
+ * A SECOND integrator for cross-checking (round 5): IDA's own algorithm - the fixed-leading-coefficient, variable-step,
+ * variable-order (1-5) BDF of DASSL / SUNDIALS IDA on modified divided differences phi[j] - restated from its published
+ * description (Brenan, Campbell, Petzold, "Numerical Solution of Initial-Value Problems in DAEs", ch. 5; SUNDIALS IDA user
+ * guide, "Mathematical considerations"; the routines named below are IDA's).  The reference integrates with this method
+ * (Assimulo's IDA, methanation_set_likelihood.py:167-198: rtol = atol = 1e-6, suppress_alg, ncp = 10 output points in NORMAL
+ * mode, so the state at t = 75 is the INTERPOLANT of the last step's polynomial).  K8 and the checker above use another
+ * formulation of the same family (SciPy's quasi-constant-step differences) with IDA's control policy; this routine answers
+ * "how far from IDA's METHOD are they" as far as that can be answered without IDA: STILL PARITY-UNPINNED - it is a restatement
+ * by the builder, never compared with SUNDIALS itself (absent from the image), and it leaves out IDACalcIC (the run starts from
+ * y'(0) = 0 like K8; the first, order-1 step absorbs the inconsistency; t = 75 is near the steady state).
+ *   IDASetCoeffs     psi, alpha, beta, sigma, gamma, alphas, alpha0, cj = -alphas / h, ck
+ *   IDAPredict       y = sum phi[j], y' = sum gamma[j] phi[j]
+ *   IDANls/NewtonIter matrix dF/dy + cj dF/dy' kept while cj / cjold in (0.6, 1/0.6), correction scaled 2 / (1 + cjratio);
+ *                    converged when ss * |delta| <= 0.33, ss carried (20 after a setup, 100 when cj changed); maxcor 4, rate > 0.9 fails
+ *   IDATestError     err_k = sigma[k] |ee|, lower-order estimates from ee + phi[k] (+ phi[k-1]); test ck |ee| <= 1
+ *   IDAHandleNFlag   error-test failures: 0.9 (2 err + 1e-4)^(-1/(k+1)) in [0.25, 0.9], then 0.25, then order 1; Newton failure: 0.25
+ *   IDACompleteStep  phase 0 (order up, h doubled every step) until a failure / order reduction / order 5; then the order
+ *                    decision from terr_{k-1}, terr_k, terr_{k+1} and h doubled if rr >= 2, reduced to [0.5, 0.9] h if rr <= 1
+ *   IDAGetSolution   interpolation at the output point
+ * ===================================================================================================================== */
+typedef struct {
+    int64_t steps, netf, ncfn, nsetups, nni, nres;
+    int32_t status;
+    int32_t order_hist[6];
+} ida_stats;
+
+static double wrms(const double *v, const double *ewt, const unsigned char *mask, int n) {
+    double s = 0.0;
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (!mask || mask[i]) {
+            const double q = v[i] * ewt[i];
+            s += q * q;
+            m++;
+        }
+    return sqrt(s / (m ? m : 1));
+}
+
+int dae_ida_integrate(resid_fn F, void *user, const double *y0, const double *p, int n, int n_fields, const unsigned char *diff_mask,
+                      double tout_final, int ncp, double rtol, double atol, double *y_out, ida_stats *st) {
+    enum { MXORD = 5, MAXCOR = 4, MAXNCF = 10, MAXNEF = 10 };
+    const double EPCON = 0.33, XRATE = 0.25, RATEMAX = 0.9;
+    double(*phi)[NS] = calloc(MXORD + 2, sizeof *phi);
+    double *ab = malloc(sizeof(double) * LDAB * NS);
+    int piv[NS];
+    double psi[MXORD + 2] = {0}, alpha[MXORD + 2] = {0}, beta[MXORD + 2] = {0}, sigma[MXORD + 2] = {0}, gamma[MXORD + 2] = {0};
+    double yy[NS], yp[NS], ee[NS], ewt[NS], delta[NS], res[NS], tmpv[NS], tv[NS];
+    memset(st, 0, sizeof *st);
+    memcpy(phi[0], y0, sizeof(double) * NS); /* phi[1] = h * y'(0) = 0 */
+    const unsigned char *emask = diff_mask;  /* suppress_alg: error tests on the differential variables; Newton norm on all */
+    double tn = 0.0;
+    /* first output point and initial step (IDASolve: hh = 0.001 * tdist, limited by 0.5 / |y'(0)| - not binding with y'(0) = 0) */
+    double hh = 0.001 * (tout_final / ncp);
+    int kk = 1, kused = 0, knew = 1, phase = 0, ns = 0, rc = 0;
+    double hused = 0.0, cj = 1.0 / hh, cjold = cj, cjlast = cj, ss = 20.0, ck = 1.0;
+    psi[0] = hh;
+    int have_matrix = 0;
+    const double cj_lo = (1 - XRATE) / (1 + XRATE), cj_hi = 1.0 / cj_lo;
+    const int64_t max_steps = 200000;
+
+    for (int icp = 1; icp <= ncp && rc == 0; ++icp) {
+        const double tout = tout_final * icp / ncp;
+        while (tn < tout && rc == 0) { /* IDAStep */
+            if (st->steps > max_steps) { rc = -1; break; }
+            for (int i = 0; i < NS; ++i) ewt[i] = 1.0 / (rtol * fabs(phi[0][i]) + atol);
+            const double saved_t = tn;
+            int ncf = 0, nef = 0;
+            double err_k = 0.0, err_km1 = 0.0;
+            for (;;) { /* attempts */
+                /* ---- IDASetCoeffs ---- */
+                if (hh != hused || kk != kused) ns = 0;
+                ns = (ns + 1 < kused + 2) ? ns + 1 : kused + 2;
+                if (kk + 1 >= ns) {
+                    beta[0] = 1.0; alpha[0] = 1.0; gamma[0] = 0.0; sigma[0] = 1.0;
+                    double temp1 = hh;
+                    for (int i = 1; i <= kk; ++i) {
+                        const double temp2 = psi[i - 1];
+                        psi[i - 1] = temp1;
+                        beta[i] = beta[i - 1] * psi[i - 1] / temp2;
+                        temp1 = temp2 + hh;
+                        alpha[i] = hh / temp1;
+                        sigma[i] = i * sigma[i - 1] * alpha[i];
+                        gamma[i] = gamma[i - 1] + alpha[i - 1] / hh;
+                    }
+                    psi[kk] = temp1;
+                }
+                double alphas = 0.0, alpha0 = 0.0;
+                for (int i = 0; i < kk; ++i) { alphas -= 1.0 / (i + 1); alpha0 -= alpha[i]; }
+                cjlast = cj;
+                cj = -alphas / hh;
+                ck = fabs(alpha[kk] + alphas - alpha0);
+                if (alpha[kk] > ck) ck = alpha[kk];
+                for (int j = ns; j <= kk; ++j)
+                    for (int i = 0; i < NS; ++i) phi[j][i] *= beta[j];
+                tn = tn + hh;
+                /* ---- IDANls ---- */
+                int call_setup = !have_matrix;
+                {
+                    const double cjratio = cj / cjold;
+                    if (cjratio < cj_lo || cjratio > cj_hi) call_setup = 1;
+                    if (cj != cjlast) ss = 100.0;
+                }
+                int nflag = 0; /* 0 ok, 1 Newton failed (recoverable), 2 error test failed */
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int i = 0; i < NS; ++i) { /* IDAPredict */
+                        double s = 0.0, q = 0.0;
+                        for (int j = 0; j <= kk; ++j) s += phi[j][i];
+                        for (int j = 1; j <= kk; ++j) q += gamma[j] * phi[j][i];
+                        yy[i] = s;
+                        yp[i] = q;
+                        ee[i] = 0.0;
+                    }
+                    int lu_ok = 1;
+                    if (call_setup) {
+                        iteration_matrix(F, user, yy, yp, p, 1.0 / cj, ab, n_fields, &st->nres);
+                        st->nsetups++;
+                        lu_ok = band_factor(ab, piv, NS) == 0;
+                        have_matrix = lu_ok;
+                        cjold = cj;
+                        ss = 20.0;
+                    }
+                    const double cjratio = cj / cjold;
+                    int conv = 0;
+                    if (lu_ok) { /* IDANewtonIter */
+                        double oldnrm = 0.0;
+                        for (int m = 0; m < MAXCOR; ++m) {
+                            F(yy, yp, p, res, user);
+                            st->nres++;
+                            st->nni++;
+                            int finite = 1;
+                            for (int i = 0; i < n; ++i)
+                                if (!isfinite(res[i])) finite = 0;
+                            if (!finite) break;
+                            for (int k2 = 0; k2 < NS; ++k2) {
+                                const int fm = fm_of_nm(k2);
+                                tmpv[k2] = (fm < n) ? res[fm] : 0.0;
+                            }
+                            band_solve(ab, piv, NS, tmpv);
+                            const double sc = (cjratio != 1.0) ? 2.0 / (1.0 + cjratio) : 1.0;
+                            for (int k2 = 0; k2 < NS; ++k2) delta[fm_of_nm(k2)] = tmpv[k2] * sc;
+                            for (int i = 0; i < n; ++i) { yy[i] -= delta[i]; ee[i] -= delta[i]; yp[i] -= cj * delta[i]; }
+                            const double delnrm = wrms(delta, ewt, NULL, n);
+                            if (m == 0) {
+                                oldnrm = delnrm;
+                                if (delnrm <= 1e-4 * EPCON) { conv = 1; break; }
+                            } else {
+                                const double rate = pow(delnrm / oldnrm, 1.0 / m);
+                                if (rate > RATEMAX) break;
+                                ss = rate / (1.0 - rate);
+                            }
+                            if (ss * delnrm <= EPCON) { conv = 1; break; }
+                        }
+                    }
+                    if (conv) { nflag = 0; break; }
+                    nflag = 1;
+                    if (call_setup) break;   /* failed with current Jacobian data */
+                    call_setup = 1;          /* retry this step with a fresh matrix (same predicted values) */
+                }
+                /* ---- IDATestError ---- */
+                if (nflag == 0) {
+                    const double enorm_k = wrms(ee, ewt, emask, n);
+                    err_k = sigma[kk] * enorm_k;
+                    const double terr_k = (kk + 1) * err_k;
+                    knew = kk;
+                    if (kk > 1) {
+                        for (int i = 0; i < NS; ++i) tv[i] = phi[kk][i] + ee[i];
+                        err_km1 = sigma[kk - 1] * wrms(tv, ewt, emask, n);
+                        const double terr_km1 = kk * err_km1;
+                        if (kk > 2) {
+                            for (int i = 0; i < NS; ++i) tv[i] += phi[kk - 1][i];
+                            const double terr_km2 = (kk - 1) * sigma[kk - 2] * wrms(tv, ewt, emask, n);
+                            if (fmax(terr_km1, terr_km2) <= terr_k) knew = kk - 1;
+                        } else if (terr_km1 <= 0.5 * terr_k) {
+                            knew = kk - 1;
+                        }
+                    }
+                    if (ck * enorm_k > 1.0) nflag = 2;
+                }
+                if (nflag == 0) break;
+                /* ---- IDARestore + IDAHandleNFlag ---- */
+                tn = saved_t;
+                for (int j = 1; j <= kk; ++j) psi[j - 1] = psi[j] - hh;
+                for (int j = ns; j <= kk; ++j)
+                    for (int i = 0; i < NS; ++i) phi[j][i] /= beta[j];
+                phase = 1;
+                if (nflag == 1) {
+                    st->ncfn++;
+                    hh *= 0.25;
+                    if (++ncf >= MAXNCF || fabs(hh) < 1e-14) { rc = -1; break; }
+                } else {
+                    st->netf++;
+                    ++nef;
+                    if (nef == 1) {
+                        const double err_knew = (kk == knew) ? err_k : err_km1;
+                        kk = knew;
+                        double rr = 0.9 * pow(2.0 * err_knew + 1e-4, -1.0 / (kk + 1));
+                        rr = fmax(0.25, fmin(0.9, rr));
+                        hh *= rr;
+                    } else if (nef == 2) {
+                        kk = knew;
+                        hh *= 0.25;
+                    } else if (nef < MAXNEF) {
+                        kk = 1;
+                        hh *= 0.25;
+                    } else { rc = -1; break; }
+                    if (fabs(hh) < 1e-14) { rc = -1; break; }
+                }
+                if (st->steps == 0) psi[0] = hh; /* still the first step */
+            }
+            if (rc) break;
+            /* ---- IDACompleteStep ---- */
+            st->steps++;
+            st->order_hist[kk]++;
+            const int kdiff = kk - kused;
+            kused = kk;
+            hused = hh;
+            if (knew == kk - 1 || kk == MXORD) phase = 1;
+            if (phase == 0) {
+                if (st->steps > 1) { kk++; hh = 2.0 * hh; }
+            } else {
+                int action = 0; /* 0 unset, 1 lower, 2 maintain, 3 raise */
+                if (knew == kk - 1) action = 1;
+                else if (kk == MXORD) action = 2;
+                else if (kk + 1 >= ns || kdiff == 1) action = 2;
+                double err_kp1 = 0.0;
+                if (action == 0) {
+                    for (int i = 0; i < NS; ++i) tv[i] = ee[i] - phi[kk + 1][i];
+                    err_kp1 = wrms(tv, ewt, emask, n) / (kk + 2);
+                    const double terr_k = (kk + 1) * err_k, terr_kp1 = (kk + 2) * err_kp1;
+                    if (kk == 1) action = (terr_kp1 >= 0.5 * terr_k) ? 2 : 3;
+                    else {
+                        const double terr_km1 = kk * err_km1;
+                        if (terr_km1 <= fmin(terr_k, terr_kp1)) action = 1;
+                        else if (terr_kp1 >= terr_k) action = 2;
+                        else action = 3;
+                    }
+                }
+                double err_knew = err_k;
+                if (action == 3) { kk++; err_knew = err_kp1; }
+                else if (action == 1) { kk--; err_knew = err_km1; }
+                double rr = pow(2.0 * err_knew + 1e-4, -1.0 / (kk + 1));
+                if (rr >= 2.0) hh = 2.0 * hh;
+                else if (rr <= 1.0) hh = hh * fmax(0.5, fmin(0.9, rr));
+            }
+            if (kused < MXORD) memcpy(phi[kused + 1], ee, sizeof(double) * NS);
+            for (int i = 0; i < NS; ++i) phi[kused][i] += ee[i];
+            for (int j = kused - 1; j >= 0; --j)
+                for (int i = 0; i < NS; ++i) phi[j][i] += phi[j + 1][i];
+        }
+    }
+    if (rc == 0) { /* IDAGetSolution at tout_final */
+        const int kord = kused ? kused : 1;
+        const double delt = tout_final - tn;
+        double c = 1.0, gam = delt / psi[0];
+        memcpy(y_out, phi[0], sizeof(double) * NS);
+        for (int j = 1; j <= kord; ++j) {
+            c = c * gam;
+            gam = (delt + psi[j - 1]) / psi[j];
+            for (int i = 0; i < NS; ++i) y_out[i] += c * phi[j][i];
+        }
+    } else {
+        memcpy(y_out, phi[0], sizeof(double) * NS);
+    }
+    st->status = rc;
+    free(phi);
+    free(ab);
+    return rc;
+}
+
+int meth_dae_solve_ida(const double *y0, const double *p, double tf, int ncp, double rtol, double atol, double *y_out, ida_stats *st) {
+    unsigned char mask[NS];
+    for (int i = 0; i < NS; ++i) mask[i] = (i < 6 * NX);
+    return dae_ida_integrate(meth_resid, NULL, y0, p, NS, 7, mask, tf, ncp, rtol, atol, y_out, st);
+}
+/* the Robertson test problem of dae_bdf_test_ode through the IDA-style integrator */
+int dae_ida_test_ode(const double *y0_3, const double *k3, double tf, double rtol, double atol, double *y3, ida_stats *st) {
+    double y0[NS], y[NS];
+    unsigned char mask[NS];
+    memset(y0, 0, sizeof y0);
+    memset(mask, 0, sizeof mask);
+    y0[0] = y0_3[0]; y0[NX] = y0_3[1]; y0[2 * NX] = y0_3[2];
+    mask[0] = mask[NX] = mask[2 * NX] = 1;
+    int rc = dae_ida_integrate(ode_resid, NULL, y0, k3, NS, 7, mask, tf, 1, rtol, atol, y, st);
+    y3[0] = y[0]; y3[1] = y[NX]; y3[2] = y[2 * NX];
+    return rc;
+}

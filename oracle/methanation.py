@@ -197,8 +197,42 @@ def dae_solve_policy(y0, p, policy=None, tf=75.0, rtol=1e-6, atol=1e-6, h0=1e-5)
     return out, rc, d
 
 
+class IdaStats(ctypes.Structure):
+    _fields_ = [("steps", ctypes.c_int64), ("netf", ctypes.c_int64), ("ncfn", ctypes.c_int64), ("nsetups", ctypes.c_int64),
+                ("nni", ctypes.c_int64), ("nres", ctypes.c_int64), ("status", ctypes.c_int32), ("order_hist", ctypes.c_int32 * 6)]
+
+    def asdict(self):
+        return {"steps": self.steps, "error_test_failures": self.netf, "newton_failures": self.ncfn, "nlu": self.nsetups,
+                "newton_iters": self.nni, "nres": self.nres, "status": self.status, "order_hist": list(self.order_hist)}
+
+
+def dae_solve_ida(y0, p, tf=75.0, ncp=10, rtol=1e-6, atol=1e-6):
+    """The same DAE through the restatement of IDA's OWN algorithm (oracle/meth_dae_oracle.c: dae_ida_integrate - fixed-leading-
+    coefficient variable-step BDF on divided differences, IDA's step / order / Newton control, interpolation at the output points):
+    a cross-check of K8's formulation, itself never compared with SUNDIALS (absent): parity stays unpinned."""
+    y0 = np.ascontiguousarray(y0, dtype=np.float64)
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    out = np.empty(7 * NX)
+    st = IdaStats()
+    rc = _dae_lib().meth_dae_solve_ida(_p(y0), _p(p), tf, int(ncp), rtol, atol, _p(out), ctypes.byref(st))
+    return out, rc, st.asdict()
+
+
+def ida_test_ode(y0, k, tf, rtol, atol):
+    y0 = np.ascontiguousarray(y0, dtype=np.float64)
+    k = np.ascontiguousarray(k, dtype=np.float64)
+    out = np.empty(3)
+    st = IdaStats()
+    rc = _dae_lib().dae_ida_test_ode(_p(y0), _p(k), tf, rtol, atol, _p(out), ctypes.byref(st))
+    return out, rc, st.asdict()
+
+
 def _dae_lib():
     L = lib()
+    L.meth_dae_solve_ida.restype = ctypes.c_int
+    L.meth_dae_solve_ida.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, _dp, ctypes.POINTER(IdaStats)]
+    L.dae_ida_test_ode.restype = ctypes.c_int
+    L.dae_ida_test_ode.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, ctypes.POINTER(IdaStats)]
     L.meth_dae_solve_policy.restype = ctypes.c_int
     L.meth_dae_solve_policy.argtypes = [_dp, _dp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp,
                                         ctypes.POINTER(DaeStats), ctypes.POINTER(DaePolicy), ctypes.POINTER(DaeStatsExt)]

@@ -74,6 +74,33 @@ def test_k8_control_policy_against_the_checker(M, setup, i):
         assert 0.8 * st0["steps"] < st1["steps"] < 1.25 * st0["steps"]
 
 
+def test_ida_algorithm_restated_agrees_with_the_bdf_formulation(M, setup):
+    """Round 5 cross-check.  K8 and the checker integrate with SciPy's quasi-constant-step formulation of the BDF family under
+    IDA's control policy; the reference integrates with IDA itself.  dae_ida_integrate restates IDA's OWN algorithm (divided
+    differences phi[j], fixed leading coefficient, its order / step rules, interpolation at the 10 output points) from its published
+    description.  Without SUNDIALS it cannot be validated either (parity stays unpinned), but two independent formulations that agree
+    at the outlet to a fraction of a tolerance unit bound what the choice of formulation can cost."""
+    from scipy.integrate import solve_ivp
+    k = [0.04, 1e4, 3e7]   # Robertson, as in the test of the BDF core
+    f = lambda t, y: [-k[0] * y[0] + k[1] * y[1] * y[2], k[0] * y[0] - k[1] * y[1] * y[2] - k[2] * y[1] ** 2, k[2] * y[1] ** 2]
+    ref = solve_ivp(f, (0, 40), [1, 0, 0], method="BDF", rtol=1e-11, atol=1e-14).y[:, -1]
+    y6, rc6, st6 = M.ida_test_ode([1, 0, 0], k, 40.0, 1e-6, 1e-10)
+    assert rc6 == 0 and np.max(np.abs(y6 - ref) / np.abs(ref)) < 2e-5 and max(np.nonzero(st6["order_hist"])[0]) >= 3
+    cond, guess = setup
+    outlet = [50, 101, 152, 203, 254, 305, 356]
+    units = lambda a, b: np.max(np.abs(a - b)[outlet] / (1e-6 + 1e-6 * np.abs(b[outlet])))
+    for i in (0, 7, 19, 29):
+        for pr in (M.BASEPARAMS, M.BASEPARAMS * np.array([3.0, 1.0, 0.3, 1.0, 1, 1, 1, 1])):
+            p = M.p0_tuple(cond, i, pr)
+            y_ida, rc, st = M.dae_solve_ida(guess[i], p)
+            y_k8, rc1, st1 = M.dae_solve_policy(guess[i], p, M.k8_policy())
+            y_ref, rc2, _ = M.dae_solve_policy(guess[i], p, None, rtol=1e-9, atol=1e-9)
+            assert rc == rc1 == rc2 == 0
+            assert units(y_ida, y_k8) < 2.0 and units(y_ida, y_ref) < 2.0
+            assert st["nlu"] < 0.2 * st["steps"] and st["newton_iters"] < 2.0 * st["steps"]      # IDA's economy: a matrix per ~12 steps
+            assert max(np.nonzero(st["order_hist"])[0]) == 5
+
+
 def test_my_model_outputs(M, setup):
     cond, guess = setup
     flows, states, stats = M.my_model(M.BASEPARAMS, cond, guess)

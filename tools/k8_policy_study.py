@@ -57,16 +57,20 @@ def main():
             "IDA all (2,1,1)": Policy(2, 1, 1, 0, 0.33, 0.25),
         }
         print(f"{len(items)} solves ({n_post} posterior-like + {n_prior} prior-box particles x 30 experiments), {cores} threads")
-        print(f"{'policy':42s} {'steps':>7s} {'rej':>5s} {'nlu':>6s} {'newton':>7s} {'nfail':>5s} {'stale':>5s} {'fail':>4s} | units vs 1e-9 run: median  p95  max | cost")
+        print(f"{'policy':54s} {'steps':>7s} {'rej':>5s} {'nlu':>6s} {'newton':>7s} {'nfail':>5s} {'stale':>5s} {'fail':>4s} | units vs 1e-9 run: median  p95  max | cost")
+        def solve_ida(it):
+            out, rc, st = OM.dae_solve_ida(it[1], it[2])
+            return out, rc, st["steps"], st["error_test_failures"], st["nlu"], st["newton_iters"], st["newton_failures"], 0
+        policies["IDA's own algorithm (divided differences, restated)"] = "ida"
         for name, pol in policies.items():
             t0 = time.time()
-            res = list(ex.map(lambda it: solve(it[1], it[2], pol), items))
+            res = list(ex.map(solve_ida if pol == "ida" else (lambda it: solve(it[1], it[2], pol)), items))
             ok = [k for k in range(len(items)) if res[k][1] == 0 and ref[k][1] == 0]
             a = np.array([[r[2], r[3], r[4], r[5], r[6], r[7]] for r in res], dtype=float)
             units = np.array([np.max(np.abs(res[k][0] - ref[k][0])[outlet] / (1e-6 + 1e-6 * np.abs(ref[k][0][outlet]))) for k in ok])
             m = a[ok].mean(axis=0)
             cost = m[2] * 60.1e3 + m[3] * 15.5e3 + (m[0] + m[1] + m[4] + m[5]) * 12e3     # cycles per solve by K8's r4 per-phase costs: factorisation, Newton iteration, rest of an attempt
-            print(f"{name:42s} {m[0]:7.1f} {m[1]:5.1f} {m[2]:6.1f} {m[3]:7.1f} {m[4]:5.2f} {m[5]:5.1f} {sum(1 for r in res if r[1] != 0):4d} | "
+            print(f"{name[:54]:54s} {m[0]:7.1f} {m[1]:5.1f} {m[2]:6.1f} {m[3]:7.1f} {m[4]:5.2f} {m[5]:5.1f} {sum(1 for r in res if r[1] != 0):4d} | "
                   f"{np.median(units):8.3f} {np.percentile(units, 95):8.2f} {units.max():8.2f} | {cost / 1e6:6.2f} M  ({time.time() - t0:.0f} s)", flush=True)
 
 
