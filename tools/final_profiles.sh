@@ -56,4 +56,6 @@ timeout -k 10 200 python3 tools/steady_state.py 1000000 1 > $O/steady.log 2>&1
 timeout -k 10 200 python3 tools/steady_state.py 10000000 1 >> $O/steady.log 2>&1
 timeout -k 10 200 python3 tools/tail_latency.py > $O/tail.log 2>&1
 timeout -k 10 200 python3 tools/user_model_bench.py 200000 > $O/user_model_bench.log 2>&1
+log "methanation N = 1024 line (with cpu_baseline)"
+timeout -k 10 300 python3 bench.py --workload methanation --particles-per-gpu 1024 --steps 1 --warmup 0 > $O/bench_methanation_n1024.json 2> $O/meth_line.err
 log "done"
