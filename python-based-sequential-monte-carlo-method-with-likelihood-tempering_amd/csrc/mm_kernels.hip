@@ -672,11 +672,12 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                  const uint8_t *__restrict__ p0_in, double *lk_io, double *filt, int64_t fstride,
                  uint8_t *__restrict__ r_ac, SweepCounters *__restrict__ counters, double *__restrict__ dbg_lk2,
                  uint8_t *__restrict__ dbg_r) {
-    __shared__ unsigned long long s_cnt[4][5];
+    __shared__ unsigned long long s_cnt[4][4];
     __shared__ double s_mom[4][9];
     if (MODE == 1 && mh.ctl && mh.ctl->stop) return;   // after the loop's `break`: p_filt, lk1, r_ac and the counters stay as they are
     unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0, long_items = 0;
-    unsigned long long solved = 0;   // items whose solve ran to t_bound and produced its n_t dense outputs (bench.py: roofline numerator)
+    // (items whose solve ran to t_bound and produced its n_t dense outputs - bench.py's roofline numerator - are counted in the HIGH
+    // half of `failed`: a reduction of its own cost 8 us per sweep, the kernel's time is its per-block tail)
     // moments of the SELECTED particles about mh.moment_shift (MODE 1, fused iteration): sum y, sum y y^T (upper), y = x - shift
     double m0 = 0, m1 = 0, m2 = 0, c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
     const bool acc_mom = (MODE == 1) && mh.moment_rows != nullptr;
@@ -709,7 +710,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                 long_items += (unsigned)(fl & kInfoAttemptsMask) > (unsigned)kLongItemAttempts;
                 pf |= (unsigned)(fl >> 30) & 1u;
                 cancelled = cancelled || (fl & kInfoCancelled) != 0;
-                solved += (fl & kInfoCancelled) == 0;
+                failed += (unsigned long long)((fl & kInfoCancelled) == 0) << 32;
             }
             failed += pf;
         }
@@ -764,7 +765,6 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
         failed += __shfl_down(failed, off);
         acc_now += __shfl_down(acc_now, off);
         acc_ever += __shfl_down(acc_ever, off);
-        solved += __shfl_down(solved, off);
     }
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
@@ -772,7 +772,6 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
         s_cnt[w][1] = failed;
         s_cnt[w][2] = acc_now;
         s_cnt[w][3] = acc_ever;
-        s_cnt[w][4] = solved;
     }
     if (acc_mom) {   // fixed-order block sums -> one row of 9 per block (deterministic; reduced by moments_reduce_kernel)
         double mv[9] = {m0, m1, m2, c00, c01, c02, c11, c12, c22};
@@ -787,13 +786,15 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
     if (acc_mom && threadIdx.x < 9)
         mh.moment_rows[(size_t)blockIdx.x * 9 + threadIdx.x] =
             ((s_mom[0][threadIdx.x] + s_mom[1][threadIdx.x]) + s_mom[2][threadIdx.x]) + s_mom[3][threadIdx.x];
-    if (threadIdx.x < 5) {
-        const unsigned long long v = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] +
-                                     s_cnt[3][threadIdx.x];
+    if (threadIdx.x < 4) {
+        unsigned long long v = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        if (threadIdx.x == 1) {      // low half: failed solves; high half: solves that produced their outputs
+            if (v >> 32) atomicAdd(&counters->solved_items, v >> 32);
+            v &= 0xffffffffULL;
+        }
         unsigned long long *dst = threadIdx.x == 0 ? &counters->rk_attempts
                                   : threadIdx.x == 1 ? &counters->n_failed
-                                  : threadIdx.x == 2 ? &counters->accepted_now
-                                  : threadIdx.x == 3 ? &counters->accepted_ever : &counters->solved_items;
+                                  : threadIdx.x == 2 ? &counters->accepted_now : &counters->accepted_ever;
         if (v) atomicAdd(dst, v);
     }
 }
