@@ -175,3 +175,17 @@ def test_run_watchdog_ends_a_rank_that_stops_making_progress():
     code1 = code.replace("run_watchdog(1, 2)", "run_watchdog(0, 1)").replace("time.sleep(30)", "time.sleep(4)")
     p = subprocess.run([sys.executable, "-c", code1], capture_output=True, text=True, timeout=60)
     assert p.returncode == 0 and "not reached" in p.stdout          # one rank: no watchdog (a long single-GPU run is not a hang)
+
+
+def test_k8_split_switch_is_parsed_as_the_library_parses_it(monkeypatch):
+    """bench.py labels the K8 roofline by the kernel SMC_K8_SPLIT selects; the library reads the switch with C's atoi
+    (csrc/meth_dae_split.h), so must bench.py - "false" or "00" are OFF for both, " 2" and "1x" are ON for both."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for v, on in [(None, True), ("0", False), ("", False), ("1", True), ("00", False), ("false", False), (" 2", True), ("-1", True), ("1x", True)]:
+        if v is None:
+            monkeypatch.delenv("SMC_K8_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("SMC_K8_SPLIT", v)
+        assert bench.k8_split_enabled() is on, v
+        assert bench.k8_kernel_name() == ("meth_particles_dae_split_kernel" if on else "meth_particles_dae_kernel")

@@ -40,8 +40,8 @@ def test_two_rank_run_follows_the_one_rank_run():
     if _visible_gpus() < 2:
         pytest.skip("needs two visible GPUs")
     n = 100_000
-    two = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--particles-per-gpu", str(n // 2), "--no-cpu-baseline")
-    one = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--particles-per-gpu", str(n), "--no-cpu-baseline")
+    two = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--particles-per-gpu", str(n // 2), "--no-cpu-baseline", "--no-extra")
+    one = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--particles-per-gpu", str(n), "--no-cpu-baseline", "--no-extra")
     assert two["n_gpus"] == 2 and two["config"]["particles_total"] == n == one["config"]["particles_total"]
     assert two["scaling"] == "weak" and two["value"] > 0
     assert two["rccl_ranks"] == 2 and len(two["per_rank_ms_per_step"]) == 2 and one["rccl_ranks"] == 0      # RCCL itself saw both ranks
