@@ -676,8 +676,9 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
     __shared__ double s_mom[4][9];
     if (MODE == 1 && mh.ctl && mh.ctl->stop) return;   // after the loop's `break`: p_filt, lk1, r_ac and the counters stay as they are
     unsigned long long attempts = 0, failed = 0, acc_now = 0, acc_ever = 0, long_items = 0;
-    // (items whose solve ran to t_bound and produced its n_t dense outputs - bench.py's roofline numerator - are counted in the HIGH
-    // half of `failed`: a reduction of its own cost 8 us per sweep, the kernel's time is its per-block tail)
+    // (items whose solve ran to t_bound and produced its n_t dense outputs - bench.py's roofline numerator - are counted in a
+    // 32-bit register and ride in the HIGH half of `failed` through the block reduction: the kernel's time is its per-block tail)
+    unsigned solved = 0;
     // moments of the SELECTED particles about mh.moment_shift (MODE 1, fused iteration): sum y, sum y y^T (upper), y = x - shift
     double m0 = 0, m1 = 0, m2 = 0, c00 = 0, c01 = 0, c02 = 0, c11 = 0, c12 = 0, c22 = 0;
     const bool acc_mom = (MODE == 1) && mh.moment_rows != nullptr;
@@ -710,7 +711,9 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
                 long_items += (unsigned)(fl & kInfoAttemptsMask) > (unsigned)kLongItemAttempts;
                 pf |= (unsigned)(fl >> 30) & 1u;
                 cancelled = cancelled || (fl & kInfoCancelled) != 0;
-                failed += (unsigned long long)((fl & kInfoCancelled) == 0) << 32;
+#ifndef SMC_NO_SOLVED_COUNT   // A/B builds
+                solved += (fl & kInfoCancelled) == 0;
+#endif
             }
             failed += pf;
         }
@@ -757,6 +760,7 @@ mm_finish_kernel(MMModel mm, MHParams mh, const double *__restrict__ theta /* ev
             }
         }
     }
+    failed += (unsigned long long)solved << 32;
     // integer reductions (order-independent): wave shuffles, LDS across the 4 waves, one atomic per block
     for (int off = 32; off > 0; off >>= 1) long_items += __shfl_down(long_items, off);
     if ((threadIdx.x & 63) == 0 && long_items) atomicAdd(&counters->long_items, long_items);
