@@ -12,7 +12,7 @@ loaded by path: `__graft_entry__.load_package()` registers it as the module `smc
 from .binding import (SMC_SET_FILT, SMC_SET_PRED, SmcError, header_symbols, lib, LIB_PATH)  # noqa: F401
 from .comm import RcclComm, SingleComm  # noqa: F401
 from .driver import SMCSettings, ess_candidates, ess_search, mvn_transform, proposal_cov, resample, run_smc, sample_prior  # noqa: F401
-from .engine import HipEngine  # noqa: F401
+from .engine import HipEngine, release_pinned_pool  # noqa: F401
 from . import methanation  # noqa: F401
 from . import datagen  # noqa: F401
 from . import user_models  # noqa: F401
