@@ -168,3 +168,54 @@ def test_batched_metropolis_loop_keeps_the_books_of_the_per_iteration_loop(pkg, 
         assert b["stats"]["mh_syncs"] == b["step"] and b["stats"]["mh_noop_sweeps"] > 0
     if mh_batch == 1:
         assert b["stats"]["mh_syncs"] == sweeps and b["stats"]["mh_noop_sweeps"] == 0
+
+
+class _ScriptedMethEngine(_ScriptedEngine):
+    """The same scripted engine presenting itself as the methanation model: every sweep has K8 work counters, which the
+    per-iteration loop reads from the engine after each sweep (meth_sweep_counters / meth_sweep_check) and the batched loop takes
+    from the batch log's per-iteration counter blocks (round 5)."""
+    model = ("methanation", 30, 357)
+
+    def _k8(self, q):
+        return {"rk_attempts": 300 * q, "newton_iters": 500 * q + 1, "factorisations": 50 * q + 2, "failed_solves": q % 3,
+                "expected_solves": 1920, "completed_solves": 1920 - 7 * q, "unsolved_items": 0, "wave_split": 0, "cancelled_solves": 7 * q}
+
+    def loglik(self, which):
+        self.last = self._k8(0)
+        return super().loglik(which)
+
+    def _one(self, ratio):
+        it = super()._one(ratio)
+        self.last = self._k8(self.q)
+        it["rk_attempts"] = self.last["rk_attempts"]
+        it["counters"] = dict(self.last)
+        return it
+
+    def mh_iteration_device_rng(self, *a, **k):
+        out = dict(super().mh_iteration_device_rng(*a, **k))
+        out.pop("counters")                      # the per-iteration call has no log: the driver asks the engine
+        return out
+
+    def meth_sweep_counters(self):
+        c = self.last
+        return {"bdf_steps": c["rk_attempts"], "newton_iters": c["newton_iters"], "factorisations": c["factorisations"], "failed_solves": c["failed_solves"]}
+
+    def meth_sweep_check(self):
+        return dict(self.last)
+
+
+@pytest.mark.parametrize("mh_batch", [2, "auto", 32])
+def test_batched_methanation_loop_accounts_k8_work_from_the_batch_log(pkg, O, data, mh_batch):
+    n = 64
+    script = [0.05, 0.3, 0.6, 0.2, 0.55, 0.04, 0.08, 0.2, 0.3, 0.9, 0.75, 0.1, 0.8]
+    runs = {}
+    for mb in (0, mh_batch):
+        eng = _ScriptedMethEngine(O, data, None, n, script)
+        runs[mb] = (pkg.run_smc(eng, pkg.SMCSettings(n_particle=n, mh_batch=mb), rng="device", verbose=False, seed_device=5), eng)
+    (a, ea), (b, eb) = runs[0], runs[mh_batch]
+    assert all(c[0] == "iter" for c in ea.calls) and all(c[0] == "batch" for c in eb.calls)      # methanation takes the batched entry point now
+    assert a["step"] == b["step"] and [r["last_j"] for r in a["records"]] == [r["last_j"] for r in b["records"]]
+    for k in ("bdf_steps", "newton_iters", "factorisations", "failed_solves", "dae_solves", "dae_solves_cancelled", "rk_attempts",
+              "mutation_sweeps", "particle_mutation_steps"):
+        assert a["stats"][k] == b["stats"][k] > 0, k
+    assert b["stats"]["mh_syncs"] <= a["stats"]["mh_syncs"]
