@@ -24,7 +24,8 @@
 // Ops (all members __device__ __forceinline__; the scheduler never looks inside an item):
 //   typename Item                        per-lane state of a started item, including where its result goes
 //   static constexpr int kPoolWords      8-byte words pack() writes
-//   long long n; int n_ex;               particles, experiments; item order (e * n_blk64 + blk) * 64 + lane (experiment-major)
+//   long long n; int n_ex;               particles, experiments; item order ((P * n_blk64 + blk) * kExPerChunk + j) * 64 + lane with experiment
+//                                        e = P * kExPerChunk + j: a chunk is ONE block of 64 particles x kExPerChunk experiments (see kExPerChunk)
 //   const int *list; unsigned n_list;    particles handed out first, or nullptr / 0
 //   const int *solo; unsigned n_solo;    particles solo[0], solo[-1], ... whose solves run one per wave on uniform operands
 //                                        from their first attempt on (the stiffest of the list), or nullptr / 0
@@ -77,6 +78,19 @@ namespace smc {
 constexpr int kSchedWave = 64;                // gfx950 wavefront
 constexpr int kChunk = SMC_CHUNK;             // item indices per global dequeue (2 per lane)
 static_assert(kChunk % 64 == 0, "a chunk is a whole number of 64-item groups");
+// Experiments a chunk covers.  Rounds 1-4 ran the index-ordered pass EXPERIMENT-MAJOR (item = (e * n_blk + blk) * 64 + lane): the
+// kChunk / 64 groups of a chunk were consecutive blocks of one experiment, and a particle's parameters (24 B, or the 32-byte
+// record of a cost-ordered sweep) were fetched from HBM once per experiment - six passes over the population by waves of
+// different XCDs, far apart in time, no cache holds them: 135 MB fetched per 10^6-particle launch where 25 MB are algorithmic
+// (profiles/r05_pmc_fetch_write_summary.json).  Now the groups of a chunk are the SAME block under consecutive experiments: the
+// wave that starts experiment e of a block starts e + 1 of it a few microseconds later and finds the parameters in its CU's /
+// XCD's cache.  A group is still one experiment (its 64 items run in phase); which items share a chunk cannot change a result.
+// SMC_EX_PER_CHUNK=1 builds the old order (A/B).
+#ifndef SMC_EX_PER_CHUNK
+#define SMC_EX_PER_CHUNK (SMC_CHUNK / 64)
+#endif
+constexpr int kExPerChunk = SMC_EX_PER_CHUNK;
+static_assert(kExPerChunk == 1 || kExPerChunk == kChunk / 64, "a chunk is one block x kExPerChunk experiments, or blocks of one experiment");
 constexpr int kRefillAt = SMC_REFILL_AT;      // idle lanes that make a wave look at its pool (and refill it when it is empty)
 constexpr int kPoolRefillFree = SMC_POOL_FREE;   // free pool slots that trigger the start of that many new items
 // Entries of the list a wave takes with one dequeue.  Fewer than a full wave on purpose: the long solves spread over many
@@ -164,10 +178,13 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
     // particles x n_ex experiments; the last group may be partial.
     const long long n_pos = ops.positions();
     const unsigned long long n_blk = (unsigned long long)((n_pos + kWave - 1) / kWave);
+    // groups of 64 items in queue order: kExPerChunk == 1: (e, blk), experiment-major; otherwise (P, blk, j) with e = P * kExPerChunk + j
+    // (n_ex need not be a multiple of kExPerChunk: the groups of the experiments beyond n_ex - 1 start nothing)
+    const unsigned n_ex_padded = (unsigned)((n_ex + kExPerChunk - 1) / kExPerChunk) * kExPerChunk;
     const unsigned n_list = ops.n_list;
     const unsigned list_cpe = (n_list + kStiffPerChunk - 1) / kStiffPerChunk;          // chunks per experiment
     const unsigned long long q_list_end = (unsigned long long)list_cpe * n_ex * kChunk;
-    const unsigned long long n_items = q_list_end + n_blk * kWave * n_ex;
+    const unsigned long long n_items = q_list_end + n_blk * kWave * n_ex_padded;
     const int lane = threadIdx.x & (kWave - 1);
 
     // ---- solo phase: the stiffest solves of the sweep, one per wave, on wave-uniform operands from their first attempt.
@@ -230,8 +247,14 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
                     q_is_list = false;
                     q_hi = (q_lo + kChunk < n_items) ? q_lo + kChunk : n_items;
                     q_grp = (q_lo - q_list_end) >> 6;
-                    q_e = (int)(q_grp / n_blk);          // experiment-major
-                    q_blk = q_grp - (unsigned long long)q_e * n_blk;
+                    if (kExPerChunk == 1) {
+                        q_e = (int)(q_grp / n_blk);          // experiment-major
+                        q_blk = q_grp - (unsigned long long)q_e * n_blk;
+                    } else {                                 // chunks are kChunk-aligned: q_grp is a multiple of kExPerChunk
+                        const unsigned long long P = q_grp / (n_blk * kExPerChunk);
+                        q_e = (int)P * kExPerChunk;          // first experiment of the chunk's block
+                        q_blk = (q_grp - P * n_blk * kExPerChunk) / kExPerChunk;
+                    }
                 }
             }
             if (!drained) {
@@ -246,13 +269,19 @@ __device__ __forceinline__ void solve_persistent(Ops &ops, unsigned long long *q
                         started = ops.start(ops.list[q_list + (unsigned)(q_lo % kChunk) + (unsigned)lane], e, true, nb) == kStartStarted;
                     } else {
                         const unsigned long long item = q_lo - q_list_end + lane;
-                        // 64-item group = (experiment, block of 64 particles); a chunk spans kChunk / 64 + 1 groups at most
-                        unsigned long long blk = q_blk + ((item >> 6) - q_grp);
+                        unsigned long long blk;
+                        if (kExPerChunk == 1) {
+                            // 64-item group = (experiment, block of 64 particles); a chunk spans kChunk / 64 + 1 groups at most
+                            blk = q_blk + ((item >> 6) - q_grp);
 #pragma unroll
-                        for (int w = 0; w < kChunk / 64 + 1; ++w)
-                            if (blk >= n_blk) { blk -= n_blk; ++e; }
+                            for (int w = 0; w < kChunk / 64 + 1; ++w)
+                                if (blk >= n_blk) { blk -= n_blk; ++e; }
+                        } else {                             // the chunk's block under experiment q_e + (group within the chunk)
+                            blk = q_blk;
+                            e += (int)((item >> 6) - q_grp);
+                        }
                         const long long pos = (long long)blk * kWave + (long long)(item & 63);
-                        if (pos < n_pos) started = ops.start_at(pos, e, nb) == kStartStarted;
+                        if (pos < n_pos && e < n_ex) started = ops.start_at(pos, e, nb) == kStartStarted;
                     }
                 }
                 const unsigned long long started_mask = __ballot(started);
