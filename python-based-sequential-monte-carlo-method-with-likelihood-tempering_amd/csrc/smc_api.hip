@@ -138,7 +138,7 @@ static int peer_host_barrier(smc_ctx *c) {
 }
 // in place over `n` doubles at buf (device): SUM or MAX over the peers
 static int peer_allreduce(smc_ctx *c, double *buf, size_t n, bool is_max, bool gather, double *gather_out) {
-    if (n * (gather ? 1 : 1) > (size_t)kPeerWords || (gather && n * c->world > (size_t)kPeerWords)) return fail(c, "local-peer collective: payload too large");
+    if (n > (size_t)kPeerWords || (gather && n * c->world > (size_t)kPeerWords)) return fail(c, "local-peer collective: payload too large");
     const int s = c->peer_parity;
     c->peer_parity ^= 1;
     double *slot = c->d_peer_contrib + (size_t)s * kPeerWords;
