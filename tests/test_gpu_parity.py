@@ -1579,3 +1579,45 @@ def test_pinned_result_arrays_outlive_their_engine_and_are_reused(pkg, data):
         out = pkg.run_smc(eng, pkg.SMCSettings(n_particle=n), rng="device", verbose=False, seed_device=2)
     assert np.isfinite(out["p_pred"]).all() and out["p_pred"].shape == (n, 3) and out["lk"].shape == (n,)
     out["p_pred"][0, 0] = 1.0                                                 # ordinary writable NumPy arrays
+
+
+def test_pinned_pool_is_thread_safe_capped_and_releasable(pkg):
+    """the pool of page-locked result buffers is shared by every engine of the process - several rank threads
+    take and give concurrently - must not keep an unbounded amount of memory pinned, and can be emptied."""
+    import gc
+    import threading
+    from smc_lt_amd import engine as E
+    pkg.release_pinned_pool()
+    assert E._PINNED.pooled == 0 and not any(E._PINNED.free.values())
+    errs = []
+
+    def work(seed):
+        try:
+            rs = np.random.RandomState(seed)
+            for _ in range(200):
+                a = E.pinned_empty((int(rs.choice([64, 256, 1024])), 3))
+                a[:] = seed
+                assert (a == seed).all()          # nobody else holds this buffer
+                del a
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    gc.collect()
+    assert not errs, errs[:1]
+    assert 0 < E._PINNED.pooled <= E._PINNED.cap_bytes
+    old_cap = E._PINNED.cap_bytes
+    try:
+        E._PINNED.cap_bytes = E._PINNED.pooled          # the pool is "full": a returned buffer is unpinned at once
+        before = E._PINNED.pooled
+        b = E.pinned_empty((5000, 3))
+        del b
+        gc.collect()
+        assert E._PINNED.pooled == before
+    finally:
+        E._PINNED.cap_bytes = old_cap
+    pkg.release_pinned_pool()
+    assert E._PINNED.pooled == 0
