@@ -448,8 +448,10 @@ class HipEngine:
                                                  at.ctypes.data_as(B.c_i64p), _dp(ru), _dp(cov), sc.ctypes.data_as(B.c_i64p)),
                  "smc_mh_sweeps_device_rng")
         its = [{"accepted_now": int(an[i]), "accepted_ever": int(ae[i]), "n_failed": int(nf[i]), "rk_attempts": int(at[i]),
-                "mhstep_ratio": float(ru[i]), "cov_m": cov[i].copy(),
-                "counters": {nm: int(sc[i, q]) for q, nm in enumerate(B.SWEEP_COUNTER_NAMES)}} for i in range(nd.value)]
+                "mhstep_ratio": float(ru[i]), "cov_m": cov[i].copy()} for i in range(nd.value)]
+        if self.model is not None and self.model[0] == "methanation":     # K8's work and completeness counters per sweep (the driver's books)
+            for i, it in enumerate(its):
+                it["counters"] = {nm: int(sc[i, q]) for q, nm in enumerate(B.SWEEP_COUNTER_NAMES)}
         return {"n_done": nd.value, "stopped": bool(st.value), "ratio_next": rn.value, "iterations": its}
 
     def proposal_factor_device(self, w_cov):
