@@ -79,6 +79,16 @@ def effective_cpus():
     return n
 
 
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_stage_times(O):
     """ESS iteration and resampling loop exactly as the reference writes them (Micmem_SMC_main.py:124-134, :147-184; NumPy
     passes and a pure-Python loop, one core), at the sizes SURVEY.md 8(d) names."""
@@ -143,7 +153,7 @@ def cpu_baseline(sample_seconds_target=4.0):
     dt_c = time.perf_counter() - t1
     assert np.max(np.abs(lk - lk_c[:m]) / np.maximum(1, np.abs(lk))) < 1e-9
     st = cpu_stage_times(O)
-    return {"value": pms / dt_run, "unit": "particle-mutation-steps/s", "cores": cores, "kind": "port",
+    return {"value": pms / dt_run, "unit": "particle-mutation-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model_name(),
             "sample": f"one COMPLETE adaptive-tempering run at N = {n} on the reference's seed (prior -> gamma = 1: {out['step']} tempering "
                       f"steps, {out['n_mutation_sweeps']} Metropolis sweeps + the initial sweep, {out['n_ess_iters']} ESS iterations), "
                       f"scipy.solve_ivp RK45 x 6 experiments per particle on a fork pool of {cores} workers, resampling loop in pure "
